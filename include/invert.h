@@ -1,0 +1,145 @@
+/*
+ * invert.h -- C ABI of the MI355X (gfx950) per-pixel hot path.
+ *
+ * The reference (ins2cvt/renderer) has no plugin or FFI seam; its hot path is the
+ * argument set of one indexed draw (src/invert.cpp:815-828) plus the attachments
+ * that draw writes (src/invert.cpp:743-750, 795-802).  Each entry point below
+ * names the reference code it stands in for.  All functions return 0 (INV_OK) or
+ * an inv_status code; inv_last_error() gives the message for the calling thread.
+ * No function aborts, throws across the boundary or frees caller memory.
+ *
+ * Threading: a context, and every scene built on it, is used by one thread at a
+ * time (the reference issues all GPU work from one renderer thread,
+ * src/invert.cpp:1865-1874).  One context per GPU / rank.
+ */
+#ifndef INVERT_H
+#define INVERT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum inv_status {
+    INV_OK = 0,
+    INV_ERR_ARG = 1,         /* null pointer, zero extent, index out of range ... */
+    INV_ERR_IO = 2,          /* file cannot be opened or read */
+    INV_ERR_FORMAT = 3,      /* OBJ text is not in the fixed format the reference loader reads */
+    INV_ERR_NOMEM = 4,
+    INV_ERR_HIP = 5,         /* a HIP runtime call failed; message carries hipGetErrorString */
+    INV_ERR_UNSUPPORTED = 6, /* e.g. a projection matrix that is not a GLM-style perspective */
+    INV_ERR_NO_DEVICE = 7,   /* no usable gfx950 device: there is no CPU fallback */
+} inv_status;
+
+typedef struct inv_ctx inv_ctx;     /* device + stream; replaces Renderer's VkDevice/VkQueue (src/invert.cpp:1483-1697) */
+typedef struct inv_mesh inv_mesh;   /* host mesh; replaces struct Obj (src/invert.cpp:25-39) */
+typedef struct inv_scene inv_scene; /* HBM-resident triangles + LBVH; replaces vertexBuffer/indexBuffer (src/invert.cpp:1113-1164) */
+
+/* UniformBufferObject (src/invert.cpp:266-271) + the vec3 push constant (src/invert.cpp:633, 817).
+ * Matrices are column-major exactly as GLM lays them out for the memcpy at src/invert.cpp:641. */
+typedef struct inv_camera {
+    float model[16];
+    float view[16];
+    float proj[16];
+    float cam_angle[3];
+} inv_camera;
+
+enum {
+    INV_LAMBERT = 1u,     /* colour *= max(0, n_geom . -cam_angle): the use of the push constant that src/shader.slang:26 leaves as a TODO */
+    INV_INVERT = 2u,      /* post-pass c' = 255 - c on R,G,B of every pixel after the sRGB encode */
+    INV_RGBA = 4u,        /* colour bytes R,G,B,A; default is B,G,R,A = VK_FORMAT_B8G8R8A8_SRGB memory order (src/invert.cpp:519) */
+    INV_BRUTE_FORCE = 8u, /* test every triangle for every ray instead of traversing the LBVH */
+};
+
+/* What the reference fixes as literals or takes from the window: extent (src/invert.cpp:779-791),
+ * one sample per pixel (src/invert.cpp:1375-1378).  spp > 1, ao_rays and the tile/rank fields extend it. */
+typedef struct inv_params {
+    uint32_t width, height;
+    uint32_t spp;     /* samples per pixel; sample 0 is the pixel centre; 0 is read as 1 */
+    uint32_t ao_rays; /* ambient-occlusion rays per hit pixel; 0 = off */
+    uint32_t flags;   /* INV_* */
+    uint32_t seed;    /* jitter / AO hash seed */
+    uint32_t tile;    /* tile edge in pixels used to shard a frame over ranks; 0 is read as 64 */
+    uint32_t rank;    /* this context renders the tiles with tile_id % nranks == rank */
+    uint32_t nranks;  /* 0 is read as 1 */
+    float ao_tmax;    /* AO ray length; 0 = scene bounding-box diagonal */
+} inv_params;
+
+/* Colour / depth attachments (src/invert.cpp:743-750, 795-802) plus a primitive-ID buffer the reference does
+ * not have.  Any pointer may be NULL to skip that output.  Row-major, width*height elements, no row padding.
+ * With nranks > 1 the buffers hold only this rank's tiles, tile after tile (see inv_tile_layout). */
+typedef struct inv_outputs {
+    void* color;    /* uint8_t[4 * n] */
+    void* depth;    /* float[n]    : z_clip / w_clip in [0,1), 1.0f where nothing was hit (clear value, src/invert.cpp:793) */
+    void* primid;   /* uint32_t[n] : index of the OBJ face, 0xFFFFFFFF where nothing was hit */
+    int on_device;  /* 0: host pointers (the call copies back and synchronises); 1: device pointers on the context's GPU (the call only enqueues) */
+} inv_outputs;
+
+/* ---- context --------------------------------------------------------------------------------------------- */
+/* Picks GPU `device` and a stream.  `hip_stream` may be an existing hipStream_t (e.g. the caller's current
+ * stream) or NULL to create one.  Fails with INV_ERR_NO_DEVICE when no HIP device is present. */
+int inv_ctx_create(int device, void* hip_stream, inv_ctx** out);
+int inv_ctx_destroy(inv_ctx* ctx);
+int inv_ctx_synchronize(inv_ctx* ctx);
+
+/* ---- mesh: struct Obj ------------------------------------------------------------------------------------ */
+/* Obj::Obj(const char*) (src/invert.cpp:42-209): same fixed text format, same float32 arithmetic, so the
+ * coordinates are bit-identical to the reference loader's.  Malformed text is INV_ERR_FORMAT (the reference
+ * has undefined behaviour there). */
+int inv_mesh_load_obj(const char* path, inv_mesh** out);
+int inv_mesh_parse_obj(const char* text, uint64_t size, inv_mesh** out);
+/* The arrays the draw binds (src/invert.cpp:826-827): float4-stride vertices (lane 3 ignored), u32 indices. */
+int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t nidx, inv_mesh** out);
+/* Obj::vertexDataSize / numIndices (src/invert.cpp:27-31, 77-79), in elements. */
+int inv_mesh_counts(const inv_mesh* mesh, uint32_t* nv, uint32_t* nidx);
+const float* inv_mesh_vertices(const inv_mesh* mesh);  /* Obj::vertexData, nv*4 floats */
+const uint32_t* inv_mesh_indices(const inv_mesh* mesh); /* Obj::indexData, nidx values, 0-based */
+int inv_mesh_destroy(inv_mesh* mesh);                   /* Obj::~Obj (src/invert.cpp:33-39) */
+
+/* ---- camera: updateUniformBuffer ------------------------------------------------------------------------- */
+/* The camera the reference hard-codes (src/invert.cpp:630-639): eye (0,0,1) looking at the origin, a 180 degree
+ * roll, 45 degree vertical field of view, near 0.1, far 10, aspect width/height, zero-to-one depth. */
+int inv_camera_reference(uint32_t width, uint32_t height, inv_camera* cam);
+
+/* ---- scene: vertex/index buffers + acceleration structure -------------------------------------------------- */
+/* Uploads the mesh (src/invert.cpp:1136-1140, 1161-1164), assembles triangle k from indices 3k..3k+2
+ * (VK_PRIMITIVE_TOPOLOGY_TRIANGLE_LIST, src/invert.cpp:1307-1310) into the HBM triangle arrays and builds the
+ * LBVH over them on the GPU.  The mesh may be destroyed afterwards. */
+int inv_scene_build(inv_ctx* ctx, const inv_mesh* mesh, inv_scene** out);
+/* Same, with `ninst` translated copies of the mesh flattened into one triangle array; primitive ID =
+ * instance * (nidx/3) + face. */
+int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* translations_xyz, uint32_t ninst,
+                              inv_scene** out);
+int inv_scene_counts(const inv_scene* scene, uint32_t* ntri, uint32_t* nnodes, uint64_t* scene_bytes);
+int inv_scene_destroy(inv_scene* scene);
+/* Copies the LBVH to host arrays (any may be NULL): morton[ntri], order[ntri] (sorted position -> triangle),
+ * child[2*(ntri-1)] (bit 31 = leaf), parent[ntri-1], leaf_parent[ntri], box[12*(ntri-1)]. */
+int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uint32_t* child, uint32_t* parent,
+                        uint32_t* leaf_parent, float* box);
+
+/* ---- the vertex stage on its own ---------------------------------------------------------------------------- */
+/* vertexShader (src/shader.slang:22-29) over every vertex of the scene's mesh: clip = P*(V*(M*(pos,1))) as three
+ * successive products, colour = (1, 1, 10*pos.z).  clip4: nv*4 floats, color3: nv*3 floats (either may be NULL). */
+int inv_vertex_shader(inv_scene* scene, const inv_camera* cam, float* clip4, float* color3, int on_device);
+
+/* ---- the draw ------------------------------------------------------------------------------------------------ */
+/* vkCmdDrawIndexed and its attachments (src/invert.cpp:743-750, 795-802, 815-828): for every pixel the visible
+ * triangle (cull BACK / front CLOCKWISE, depth LESS against a 1.0 clear, lower primitive wins ties:
+ * src/invert.cpp:1331-1337, 1380-1385), its depth and its colour (src/shader.slang:27, 31-36) stored as sRGB8. */
+int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out);
+
+/* Number of pixels rank `rank` owns and, optionally, the tile ids in the order they are stored. */
+int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_ids, uint32_t tile_ids_cap,
+                    uint32_t* ntiles);
+/* Rank 0 after the gather: scatter `nranks` tile-major buffers (concatenated in rank order) into one row-major
+ * frame.  Device pointers on the context's GPU; elem_size is 4 for every attachment. */
+int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, void* frame, uint32_t elem_size);
+
+const char* inv_last_error(void);
+const char* inv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INVERT_H */

@@ -1,0 +1,264 @@
+"""ctypes binding of libinvert_hip.so (include/invert.h).
+
+This is plumbing around the C ABI: device memory comes from the caller (numpy host
+arrays or torch device tensors), every pixel is computed by the HIP library.  There
+is no CPU fallback: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinvert_hip.so")
+
+LAMBERT, INVERT, RGBA, BRUTE_FORCE = 1, 2, 4, 8
+OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(8)
+
+# every symbol include/invert.h declares
+SYMBOLS = (
+    "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize",
+    "inv_mesh_load_obj", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
+    "inv_mesh_indices", "inv_mesh_destroy",
+    "inv_camera_reference",
+    "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
+    "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
+    "inv_last_error", "inv_version",
+)
+
+
+class Camera(C.Structure):
+    """inv_camera: UniformBufferObject + push constant (reference src/invert.cpp:266-271, 633)."""
+    _fields_ = [("model", C.c_float * 16), ("view", C.c_float * 16), ("proj", C.c_float * 16),
+                ("cam_angle", C.c_float * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("ao_rays", C.c_uint32),
+                ("flags", C.c_uint32), ("seed", C.c_uint32), ("tile", C.c_uint32), ("rank", C.c_uint32),
+                ("nranks", C.c_uint32), ("ao_tmax", C.c_float)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("depth", C.c_void_p), ("primid", C.c_void_p), ("on_device", C.c_int)]
+
+
+class InvertError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("inv error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (there is no other implementation)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C renderer_amd/csrc` (hipcc, gfx950); "
+                          "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32p, u64p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.inv_last_error.restype = C.c_char_p
+    L.inv_version.restype = C.c_char_p
+    L.inv_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.inv_ctx_destroy.argtypes = [vp]
+    L.inv_ctx_synchronize.argtypes = [vp]
+    L.inv_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.inv_mesh_parse_obj.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(vp)]
+    L.inv_mesh_from_arrays.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
+    L.inv_mesh_counts.argtypes = [vp, u32p, u32p]
+    L.inv_mesh_vertices.argtypes = [vp]
+    L.inv_mesh_vertices.restype = C.POINTER(C.c_float)
+    L.inv_mesh_indices.argtypes = [vp]
+    L.inv_mesh_indices.restype = u32p
+    L.inv_mesh_destroy.argtypes = [vp]
+    L.inv_camera_reference.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera)]
+    L.inv_scene_build.argtypes = [vp, vp, C.POINTER(vp)]
+    L.inv_scene_build_instanced.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(vp)]
+    L.inv_scene_counts.argtypes = [vp, u32p, u32p, u64p]
+    L.inv_scene_destroy.argtypes = [vp]
+    L.inv_scene_read_lbvh.argtypes = [vp] + [vp] * 6
+    L.inv_vertex_shader.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int]
+    L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
+    L.inv_tile_layout.argtypes = [C.POINTER(Params), u64p, u32p, C.c_uint32, u32p]
+    L.inv_deinterleave.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_uint32]
+    _lib = L
+    return L
+
+
+def _chk(rc: int) -> None:
+    if rc != 0:
+        raise InvertError(rc, lib().inv_last_error().decode(errors="replace"))
+
+
+def version() -> str:
+    return lib().inv_version().decode()
+
+
+def make_params(width, height, spp=1, ao_rays=0, flags=0, seed=0, tile=0, rank=0, nranks=1, ao_tmax=0.0) -> Params:
+    return Params(width, height, spp, ao_rays, flags, seed, tile, rank, nranks, ao_tmax)
+
+
+def camera_reference(width: int, height: int) -> Camera:
+    """The reference's hard-coded camera (src/invert.cpp:630-639)."""
+    cam = Camera()
+    _chk(lib().inv_camera_reference(width, height, C.byref(cam)))
+    return cam
+
+
+class Mesh:
+    """Host mesh: the reference's struct Obj (src/invert.cpp:25-39)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def load_obj(path: str) -> "Mesh":
+        h = C.c_void_p()
+        _chk(lib().inv_mesh_load_obj(os.fsencode(path), C.byref(h)))
+        return Mesh(h)
+
+    @staticmethod
+    def parse_obj(text: bytes) -> "Mesh":
+        h = C.c_void_p()
+        _chk(lib().inv_mesh_parse_obj(text, len(text), C.byref(h)))
+        return Mesh(h)
+
+    @staticmethod
+    def from_arrays(xyzw: np.ndarray, idx: np.ndarray) -> "Mesh":
+        xyzw = np.ascontiguousarray(xyzw, np.float32).reshape(-1, 4)
+        idx = np.ascontiguousarray(idx, np.uint32).reshape(-1)
+        h = C.c_void_p()
+        _chk(lib().inv_mesh_from_arrays(xyzw.ctypes.data, xyzw.shape[0], idx.ctypes.data, idx.size, C.byref(h)))
+        return Mesh(h)
+
+    def counts(self):
+        nv, nidx = C.c_uint32(), C.c_uint32()
+        _chk(lib().inv_mesh_counts(self._h, C.byref(nv), C.byref(nidx)))
+        return nv.value, nidx.value
+
+    @property
+    def vertices(self) -> np.ndarray:
+        nv, _ = self.counts()
+        if nv == 0:
+            return np.zeros((0, 4), np.float32)
+        return np.ctypeslib.as_array(lib().inv_mesh_vertices(self._h), shape=(nv * 4,)).reshape(nv, 4).copy()
+
+    @property
+    def indices(self) -> np.ndarray:
+        _, nidx = self.counts()
+        if nidx == 0:
+            return np.zeros(0, np.uint32)
+        return np.ctypeslib.as_array(lib().inv_mesh_indices(self._h), shape=(nidx,)).copy()
+
+    def close(self):
+        if self._h:
+            lib().inv_mesh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one stream (pass torch's current stream handle to share it)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        _chk(lib().inv_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def synchronize(self):
+        _chk(lib().inv_ctx_synchronize(self._h))
+
+    def deinterleave(self, prm: Params, gathered_ptr: int, frame_ptr: int):
+        _chk(lib().inv_deinterleave(self._h, C.byref(prm), C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), 4))
+
+    def close(self):
+        if self._h:
+            lib().inv_ctx_destroy(self._h)
+            self._h = None
+
+
+def tile_layout(prm: Params):
+    """(pixels stored by this rank, tile ids in storage order)."""
+    npix, nt = C.c_uint64(), C.c_uint32()
+    _chk(lib().inv_tile_layout(C.byref(prm), C.byref(npix), None, 0, C.byref(nt)))
+    ids = np.zeros(max(nt.value, 1), np.uint32)
+    _chk(lib().inv_tile_layout(C.byref(prm), C.byref(npix), ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size,
+                               C.byref(nt)))
+    return npix.value, ids[:nt.value]
+
+
+class Scene:
+    """HBM-resident triangles + LBVH for one mesh (optionally instanced)."""
+
+    def __init__(self, ctx: Context, mesh: Mesh, translations: np.ndarray | None = None):
+        h = C.c_void_p()
+        if translations is None:
+            _chk(lib().inv_scene_build(ctx._h, mesh._h, C.byref(h)))
+        else:
+            tr = np.ascontiguousarray(translations, np.float32).reshape(-1, 3)
+            _chk(lib().inv_scene_build_instanced(ctx._h, mesh._h, tr.ctypes.data, tr.shape[0], C.byref(h)))
+        self._h = h
+        self.ctx = ctx
+        self.nv, _ = mesh.counts()
+
+    def counts(self):
+        ntri, nnodes, nbytes = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _chk(lib().inv_scene_counts(self._h, C.byref(ntri), C.byref(nnodes), C.byref(nbytes)))
+        return ntri.value, nnodes.value, nbytes.value
+
+    def read_lbvh(self):
+        n, _, _ = self.counts()
+        m = max(n - 1, 0)
+        out = dict(morton=np.zeros(n, np.uint64), order=np.zeros(n, np.uint32), child=np.zeros((m, 2), np.uint32),
+                   parent=np.zeros(m, np.uint32), leaf_parent=np.zeros(n, np.uint32), box=np.zeros((m, 12), np.float32))
+        _chk(lib().inv_scene_read_lbvh(self._h, out["morton"].ctypes.data, out["order"].ctypes.data,
+                                       out["child"].ctypes.data, out["parent"].ctypes.data,
+                                       out["leaf_parent"].ctypes.data, out["box"].ctypes.data))
+        return out
+
+    def vertex_shader(self, cam: Camera):
+        """vertexShader over the mesh (reference src/shader.slang:22-29): (clip [nv,4], colour [nv,3])."""
+        clip = np.zeros((self.nv, 4), np.float32)
+        col = np.zeros((self.nv, 3), np.float32)
+        _chk(lib().inv_vertex_shader(self._h, C.byref(cam), clip.ctypes.data, col.ctypes.data, 0))
+        return clip, col
+
+    def render(self, cam: Camera, prm: Params):
+        """The draw into host arrays: (colour u8 [h,w,4], depth f32 [h,w], primid u32 [h,w]).
+
+        With nranks > 1 the arrays are this rank's tile slots, shape [slots, tile, tile(,4)].
+        """
+        npix, _ = tile_layout(prm)
+        color = np.empty(npix * 4, np.uint8)
+        depth = np.empty(npix, np.float32)
+        primid = np.empty(npix, np.uint32)
+        out = Outputs(color.ctypes.data, depth.ctypes.data, primid.ctypes.data, 0)
+        _chk(lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(out)))
+        if (prm.nranks or 1) <= 1:
+            h, w = prm.height, prm.width
+            return color.reshape(h, w, 4), depth.reshape(h, w), primid.reshape(h, w)
+        t = prm.tile or 64
+        return color.reshape(-1, t, t, 4), depth.reshape(-1, t, t), primid.reshape(-1, t, t)
+
+    def render_device(self, cam: Camera, prm: Params, color_ptr: int = 0, depth_ptr: int = 0, primid_ptr: int = 0):
+        """Enqueue the draw into device buffers (e.g. torch tensors' data_ptr()) on the context's stream."""
+        out = Outputs(color_ptr or None, depth_ptr or None, primid_ptr or None, 1)
+        _chk(lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(out)))
+
+    def close(self):
+        if self._h:
+            lib().inv_scene_destroy(self._h)
+            self._h = None

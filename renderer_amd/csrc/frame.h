@@ -1,0 +1,33 @@
+// Per-frame constants and output pointers shared by host and device code.
+#pragma once
+
+#include <stdint.h>
+
+namespace inv {
+
+// Per-frame constants: what the reference passes as the uniform buffer, the push
+// constant and the dynamic viewport (src/invert.cpp:266-271, 779-791, 817),
+// reduced on the host to the terms the kernels use.
+struct FrameK {
+    float ox, oy, oz;    // ray origin in object space (inverse of view*model applied to the eye)
+    float d0x, d0y, d0z; // columns of the 3x3 that carries a view-space direction to object space
+    float d1x, d1y, d1z;
+    float d2x, d2y, d2z;
+    float p00, p11, p22, p32; // GLM perspective terms proj[0][0], [1][1], [2][2], [3][2]
+    float pad;                // guard pad: 2^-16 * max(|origin|, |scene coordinates|)
+    float lx, ly, lz;         // unit direction towards the light in object space (Lambert); 0 if undefined
+    float wf, hf;
+    uint32_t w, h;
+    uint32_t spp, flags, seed;
+    // tile sharding
+    uint32_t tile, rank, nranks, tiles_x, ntiles, slots; // slots = tiles stored per rank
+    uint64_t npix;                                       // pixels this launch covers
+};
+
+struct Outputs {
+    uint8_t* color;
+    float* depth;
+    uint32_t* primid;
+};
+
+} // namespace inv

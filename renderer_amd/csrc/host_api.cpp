@@ -1,0 +1,419 @@
+// C ABI (include/invert.h): handles, argument checks, error strings and the host side of the draw.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "internal.h"
+
+namespace inv {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char* what) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    return fail(INV_ERR_HIP, buf);
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+} // namespace inv
+
+using namespace inv;
+
+struct inv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+};
+
+struct inv_mesh {
+    std::vector<float> xyzw;
+    std::vector<uint32_t> idx;
+};
+
+struct inv_scene {
+    inv_ctx* ctx = nullptr;
+    DeviceScene d;
+    float max_abs = 0.0f;
+    // device staging for host-pointer outputs (grow-only)
+    void* stage[3] = {nullptr, nullptr, nullptr};
+    uint64_t stage_elems = 0;
+    float* vs_stage = nullptr;
+    uint64_t vs_stage_floats = 0;
+};
+
+namespace {
+
+template <class T>
+void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_device_scene(DeviceScene& d) {
+    dfree(d.xyzw), dfree(d.idx), dfree(d.triA), dfree(d.triB), dfree(d.triC);
+    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.box), dfree(d.nodes);
+}
+
+// Tile sharding terms of a frame (one rank: row-major, several: tile slots).
+int fill_layout(const inv_params& p, FrameK* f) {
+    if (p.width == 0 || p.height == 0) return fail(INV_ERR_ARG, "params: width and height must be non-zero");
+    if ((uint64_t)p.width * p.height > 0x7FFFFFFFull) return fail(INV_ERR_ARG, "params: more than 2^31 pixels");
+    f->w = p.width, f->h = p.height;
+    f->wf = (float)p.width, f->hf = (float)p.height;
+    f->spp = p.spp ? p.spp : 1u;
+    f->flags = p.flags;
+    f->seed = p.seed;
+    f->tile = p.tile ? p.tile : 64u;
+    f->nranks = p.nranks ? p.nranks : 1u;
+    f->rank = p.rank;
+    if (f->rank >= f->nranks) return fail(INV_ERR_ARG, "params: rank must be below nranks");
+    if (f->tile > 1024u || (f->tile & 7u)) return fail(INV_ERR_ARG, "params: tile must be a multiple of 8, at most 1024");
+    f->tiles_x = (p.width + f->tile - 1) / f->tile;
+    uint32_t tiles_y = (p.height + f->tile - 1) / f->tile;
+    f->ntiles = f->tiles_x * tiles_y;
+    f->slots = (f->ntiles + f->nranks - 1) / f->nranks;
+    f->npix = f->nranks == 1 ? (uint64_t)p.width * p.height : (uint64_t)f->slots * f->tile * f->tile;
+    return INV_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* inv_last_error(void) { return g_last_error.c_str(); }
+const char* inv_version(void) { return "invert-mi355x 0.1 (gfx950)"; }
+
+// ---- context -------------------------------------------------------------------------------------
+int inv_ctx_create(int device, void* hip_stream, inv_ctx** out) {
+    if (!out) return fail(INV_ERR_ARG, "inv_ctx_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(INV_ERR_NO_DEVICE, "inv_ctx_create: no HIP device is visible; this library has no CPU path");
+    if (device < 0 || device >= count) return fail(INV_ERR_ARG, "inv_ctx_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    inv_ctx* c = new (std::nothrow) inv_ctx;
+    if (!c) return fail(INV_ERR_NOMEM, "inv_ctx_create: out of memory");
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return hip_fail(e, "hipStreamCreateWithFlags");
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return INV_OK;
+}
+
+int inv_ctx_destroy(inv_ctx* ctx) {
+    if (!ctx) return INV_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return INV_OK;
+}
+
+int inv_ctx_synchronize(inv_ctx* ctx) {
+    if (!ctx) return fail(INV_ERR_ARG, "inv_ctx_synchronize: ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return INV_OK;
+}
+
+// ---- mesh ----------------------------------------------------------------------------------------
+int inv_mesh_parse_obj(const char* text, uint64_t size, inv_mesh** out) {
+    if (!out) return fail(INV_ERR_ARG, "inv_mesh_parse_obj: out is null");
+    *out = nullptr;
+    inv_mesh* m = new (std::nothrow) inv_mesh;
+    if (!m) return fail(INV_ERR_NOMEM, "inv_mesh_parse_obj: out of memory");
+    int rc = parse_obj_text(text, size, m->xyzw, m->idx);
+    if (rc != INV_OK) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return INV_OK;
+}
+
+int inv_mesh_load_obj(const char* path, inv_mesh** out) {
+    if (!out) return fail(INV_ERR_ARG, "inv_mesh_load_obj: out is null");
+    *out = nullptr;
+    if (!path) return fail(INV_ERR_ARG, "inv_mesh_load_obj: path is null");
+    FILE* fp = std::fopen(path, "rb"); // whole-file read (src/invert.cpp:44-50); a missing file is an error here
+    if (!fp) return fail(INV_ERR_IO, std::string("inv_mesh_load_obj: cannot open ") + path);
+    std::vector<char> text;
+    char chunk[1 << 16];
+    size_t got;
+    while ((got = std::fread(chunk, 1, sizeof chunk, fp)) > 0) text.insert(text.end(), chunk, chunk + got);
+    bool bad = std::ferror(fp) != 0;
+    std::fclose(fp);
+    if (bad) return fail(INV_ERR_IO, std::string("inv_mesh_load_obj: read error on ") + path);
+    return inv_mesh_parse_obj(text.data(), text.size(), out);
+}
+
+int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t nidx, inv_mesh** out) {
+    if (!out) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: out is null");
+    *out = nullptr;
+    if ((nv && !xyzw) || (nidx && !idx)) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: null array");
+    if (nidx % 3u) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: nidx must be a multiple of 3 (triangle list)");
+    for (uint32_t i = 0; i < nidx; i++)
+        if (idx[i] >= nv) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: index out of range");
+    inv_mesh* m = new (std::nothrow) inv_mesh;
+    if (!m) return fail(INV_ERR_NOMEM, "inv_mesh_from_arrays: out of memory");
+    m->xyzw.assign(xyzw, xyzw + (size_t)nv * 4);
+    m->idx.assign(idx, idx + nidx);
+    *out = m;
+    return INV_OK;
+}
+
+int inv_mesh_counts(const inv_mesh* mesh, uint32_t* nv, uint32_t* nidx) {
+    if (!mesh) return fail(INV_ERR_ARG, "inv_mesh_counts: mesh is null");
+    if (nv) *nv = (uint32_t)(mesh->xyzw.size() / 4);
+    if (nidx) *nidx = (uint32_t)mesh->idx.size();
+    return INV_OK;
+}
+
+const float* inv_mesh_vertices(const inv_mesh* mesh) { return mesh ? mesh->xyzw.data() : nullptr; }
+const uint32_t* inv_mesh_indices(const inv_mesh* mesh) { return mesh ? mesh->idx.data() : nullptr; }
+
+int inv_mesh_destroy(inv_mesh* mesh) {
+    delete mesh;
+    return INV_OK;
+}
+
+// ---- camera --------------------------------------------------------------------------------------
+int inv_camera_reference(uint32_t width, uint32_t height, inv_camera* cam) {
+    if (!cam) return fail(INV_ERR_ARG, "inv_camera_reference: cam is null");
+    if (width == 0 || height == 0) return fail(INV_ERR_ARG, "inv_camera_reference: zero extent");
+    reference_camera(width, height, cam);
+    return INV_OK;
+}
+
+// ---- scene ---------------------------------------------------------------------------------------
+int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* translations_xyz, uint32_t ninst,
+                              inv_scene** out) {
+    if (!out) return fail(INV_ERR_ARG, "inv_scene_build: out is null");
+    *out = nullptr;
+    if (!ctx || !mesh) return fail(INV_ERR_ARG, "inv_scene_build: ctx or mesh is null");
+    if (ninst == 0) return fail(INV_ERR_ARG, "inv_scene_build: ninst must be at least 1");
+    const uint32_t nv = (uint32_t)(mesh->xyzw.size() / 4);
+    const uint32_t base_ntri = (uint32_t)(mesh->idx.size() / 3);
+    const uint64_t ntri64 = (uint64_t)base_ntri * ninst;
+    if (ntri64 >= 0x7FFFFFFFull) return fail(INV_ERR_ARG, "inv_scene_build: more than 2^31 triangles");
+    HIP_TRY(hipSetDevice(ctx->device));
+    inv_scene* s = new (std::nothrow) inv_scene;
+    if (!s) return fail(INV_ERR_NOMEM, "inv_scene_build: out of memory");
+    s->ctx = ctx;
+    DeviceScene& d = s->d;
+    d.nv = nv;
+    d.ntri = (uint32_t)ntri64;
+    // largest |coordinate| the rays can meet (feeds the guard pad)
+    float max_abs = 0.0f;
+    for (uint32_t i = 0; i < nv; i++)
+        for (int c = 0; c < 3; c++) {
+            float v = mesh->xyzw[(size_t)i * 4 + c];
+            if (translations_xyz) {
+                for (uint32_t j = 0; j < ninst; j++) max_abs = std::fmax(max_abs, std::fabs(v + translations_xyz[(size_t)j * 3 + c]));
+            } else {
+                max_abs = std::fmax(max_abs, std::fabs(v));
+            }
+        }
+    s->max_abs = max_abs;
+    float* d_tr = nullptr;
+    int rc = INV_OK;
+    hipError_t e = hipSuccess;
+    auto bail = [&](hipError_t err, const char* what) {
+        rc = hip_fail(err, what);
+        if (d_tr) (void)hipFree(d_tr);
+        free_device_scene(d);
+        delete s;
+        return rc;
+    };
+    if (nv) {
+        if ((e = hipMalloc((void**)&d.xyzw, (size_t)nv * 16)) != hipSuccess) return bail(e, "hipMalloc(vertices)");
+        // host-visible copy of the Obj arrays (src/invert.cpp:1136-1140, 1161-1164)
+        if ((e = hipMemcpyAsync(d.xyzw, mesh->xyzw.data(), (size_t)nv * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return bail(e, "hipMemcpyAsync(vertices)");
+    }
+    if (base_ntri) {
+        if ((e = hipMalloc((void**)&d.idx, (size_t)base_ntri * 12)) != hipSuccess) return bail(e, "hipMalloc(indices)");
+        if ((e = hipMemcpyAsync(d.idx, mesh->idx.data(), (size_t)base_ntri * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return bail(e, "hipMemcpyAsync(indices)");
+    }
+    if (d.ntri) {
+        if ((e = hipMalloc((void**)&d.triA, (size_t)d.ntri * 16)) != hipSuccess) return bail(e, "hipMalloc(triA)");
+        if ((e = hipMalloc((void**)&d.triB, (size_t)d.ntri * 16)) != hipSuccess) return bail(e, "hipMalloc(triB)");
+        if ((e = hipMalloc((void**)&d.triC, (size_t)d.ntri * 16)) != hipSuccess) return bail(e, "hipMalloc(triC)");
+        if (translations_xyz) {
+            if ((e = hipMalloc((void**)&d_tr, (size_t)ninst * 12)) != hipSuccess) return bail(e, "hipMalloc(translations)");
+            if ((e = hipMemcpyAsync(d_tr, translations_xyz, (size_t)ninst * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+                return bail(e, "hipMemcpyAsync(translations)");
+        }
+        if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, d.triA, d.triB, d.triC)) != hipSuccess)
+            return bail(e, "assemble kernel");
+        if ((e = build_lbvh(ctx->stream, d)) != hipSuccess) return bail(e, "LBVH build");
+    }
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
+    if (d_tr) (void)hipFree(d_tr);
+    *out = s;
+    return INV_OK;
+}
+
+int inv_scene_build(inv_ctx* ctx, const inv_mesh* mesh, inv_scene** out) {
+    return inv_scene_build_instanced(ctx, mesh, nullptr, 1, out);
+}
+
+int inv_scene_counts(const inv_scene* scene, uint32_t* ntri, uint32_t* nnodes, uint64_t* scene_bytes) {
+    if (!scene) return fail(INV_ERR_ARG, "inv_scene_counts: scene is null");
+    uint32_t n = scene->d.ntri;
+    uint32_t nodes = (scene->d.has_bvh && n >= 2) ? n - 1 : 0;
+    if (ntri) *ntri = n;
+    if (nnodes) *nnodes = nodes;
+    if (scene_bytes) *scene_bytes = (uint64_t)n * 48 + (uint64_t)nodes * 64;
+    return INV_OK;
+}
+
+int inv_scene_destroy(inv_scene* scene) {
+    if (!scene) return INV_OK;
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    free_device_scene(scene->d);
+    for (auto& p : scene->stage) dfree(p);
+    dfree(scene->vs_stage);
+    delete scene;
+    return INV_OK;
+}
+
+int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uint32_t* child, uint32_t* parent,
+                        uint32_t* leaf_parent, float* box) {
+    if (!scene) return fail(INV_ERR_ARG, "inv_scene_read_lbvh: scene is null");
+    const DeviceScene& d = scene->d;
+    if (!d.has_bvh) return fail(INV_ERR_ARG, "inv_scene_read_lbvh: the scene has no LBVH (fewer than 2 triangles)");
+    HIP_TRY(hipSetDevice(scene->ctx->device));
+    HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
+    size_t n = d.ntri;
+    if (morton) HIP_TRY(hipMemcpy(morton, d.morton, n * 8, hipMemcpyDeviceToHost));
+    if (order) HIP_TRY(hipMemcpy(order, d.order, n * 4, hipMemcpyDeviceToHost));
+    if (child) HIP_TRY(hipMemcpy(child, d.child, (n - 1) * 8, hipMemcpyDeviceToHost));
+    if (parent) HIP_TRY(hipMemcpy(parent, d.parent, (n - 1) * 4, hipMemcpyDeviceToHost));
+    if (leaf_parent) HIP_TRY(hipMemcpy(leaf_parent, d.leaf_parent, n * 4, hipMemcpyDeviceToHost));
+    if (box) HIP_TRY(hipMemcpy(box, d.box, (n - 1) * 48, hipMemcpyDeviceToHost));
+    return INV_OK;
+}
+
+// ---- vertex stage ----------------------------------------------------------------------------------
+int inv_vertex_shader(inv_scene* scene, const inv_camera* cam, float* clip4, float* color3, int on_device) {
+    if (!scene || !cam) return fail(INV_ERR_ARG, "inv_vertex_shader: scene or cam is null");
+    inv_ctx* ctx = scene->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t nv = scene->d.nv;
+    if (on_device) {
+        HIP_TRY(launch_vertex_shader(ctx->stream, scene->d.xyzw, nv, *cam, clip4, color3));
+        return INV_OK;
+    }
+    uint64_t need = (uint64_t)nv * 7;
+    if (need > scene->vs_stage_floats) {
+        dfree(scene->vs_stage);
+        HIP_TRY(hipMalloc((void**)&scene->vs_stage, need * 4));
+        scene->vs_stage_floats = need;
+    }
+    float* dclip = clip4 ? scene->vs_stage : nullptr;
+    float* dcol = color3 ? scene->vs_stage + (size_t)nv * 4 : nullptr;
+    HIP_TRY(launch_vertex_shader(ctx->stream, scene->d.xyzw, nv, *cam, dclip, dcol));
+    if (clip4) HIP_TRY(hipMemcpyAsync(clip4, dclip, (size_t)nv * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (color3) HIP_TRY(hipMemcpyAsync(color3, dcol, (size_t)nv * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return INV_OK;
+}
+
+// ---- the draw ----------------------------------------------------------------------------------------
+int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out) {
+    if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render: null argument");
+    if (params->ao_rays != 0) return fail(INV_ERR_UNSUPPORTED, "inv_render: ambient occlusion is not available in this build");
+    inv_ctx* ctx = scene->ctx;
+    FrameK f;
+    std::memset(&f, 0, sizeof f);
+    int rc = fill_layout(*params, &f);
+    if (rc != INV_OK) return rc;
+    if ((rc = frame_from_camera(*cam, scene->max_abs, &f)) != INV_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Outputs dev = {nullptr, nullptr, nullptr};
+    if (out->on_device) {
+        dev.color = (uint8_t*)out->color, dev.depth = (float*)out->depth, dev.primid = (uint32_t*)out->primid;
+    } else {
+        if (f.npix > scene->stage_elems) {
+            for (auto& p : scene->stage) dfree(p);
+            scene->stage_elems = 0;
+            for (auto& p : scene->stage) HIP_TRY(hipMalloc(&p, f.npix * 4));
+            scene->stage_elems = f.npix;
+        }
+        if (out->color) dev.color = (uint8_t*)scene->stage[0];
+        if (out->depth) dev.depth = (float*)scene->stage[1];
+        if (out->primid) dev.primid = (uint32_t*)scene->stage[2];
+    }
+    const bool brute = (params->flags & INV_BRUTE_FORCE) || !scene->d.has_bvh;
+    if (brute)
+        HIP_TRY(launch_render_brute(ctx->stream, f, scene->d, dev));
+    else
+        HIP_TRY(launch_render_bvh(ctx->stream, f, scene->d, dev));
+    if (!out->on_device) {
+        if (out->color) HIP_TRY(hipMemcpyAsync(out->color, dev.color, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->depth) HIP_TRY(hipMemcpyAsync(out->depth, dev.depth, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->primid) HIP_TRY(hipMemcpyAsync(out->primid, dev.primid, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return INV_OK;
+}
+
+int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_ids, uint32_t tile_ids_cap,
+                    uint32_t* ntiles) {
+    if (!params) return fail(INV_ERR_ARG, "inv_tile_layout: params is null");
+    FrameK f;
+    std::memset(&f, 0, sizeof f);
+    int rc = fill_layout(*params, &f);
+    if (rc != INV_OK) return rc;
+    if (npixels) *npixels = f.npix;
+    uint32_t count = 0;
+    for (uint32_t slot = 0; slot < f.slots; slot++) {
+        uint32_t id = slot * f.nranks + f.rank;
+        if (id >= f.ntiles) break;
+        if (tile_ids && count < tile_ids_cap) tile_ids[count] = id;
+        count++;
+    }
+    if (ntiles) *ntiles = count;
+    return INV_OK;
+}
+
+int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, void* frame, uint32_t elem_size) {
+    if (!ctx || !params || !gathered || !frame) return fail(INV_ERR_ARG, "inv_deinterleave: null argument");
+    if (elem_size != 4) return fail(INV_ERR_ARG, "inv_deinterleave: elem_size must be 4");
+    FrameK f;
+    std::memset(&f, 0, sizeof f);
+    inv_params p = *params;
+    p.rank = 0;
+    int rc = fill_layout(p, &f);
+    if (rc != INV_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_deinterleave(ctx->stream, f, (const uint32_t*)gathered, (uint32_t*)frame));
+    return INV_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,56 @@
+// Host-side declarations shared by the C ABI, the loader, the camera and the kernel launchers.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/invert.h"
+#include "frame.h"
+
+namespace inv {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+// A1 -- obj_loader.cpp
+int parse_obj_text(const char* text, uint64_t size, std::vector<float>& xyzw, std::vector<uint32_t>& idx);
+
+// A2 -- camera.cpp
+void reference_camera(uint32_t width, uint32_t height, inv_camera* cam);
+// view*model, its inverse (double Gauss-Jordan rounded to float) and the Lambert light direction.
+int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f);
+
+// kernels.hip -- launchers (all asynchronous on `stream`)
+struct DeviceScene {
+    uint32_t nv = 0, ntri = 0;
+    float* xyzw = nullptr;    // nv float4 (mesh vertices as uploaded)
+    uint32_t* idx = nullptr;  // 3 * base_ntri indices
+    float* triA = nullptr;    // ntri float4 each, storage order (LBVH order once built)
+    float* triB = nullptr;
+    float* triC = nullptr;
+    // LBVH
+    uint64_t* morton = nullptr;    // ntri, sorted
+    uint32_t* order = nullptr;     // ntri: storage slot -> primitive id
+    uint32_t* child = nullptr;     // 2*(ntri-1)
+    uint32_t* parent = nullptr;    // ntri-1
+    uint32_t* leaf_parent = nullptr; // ntri
+    float* box = nullptr;          // 12*(ntri-1)
+    float* nodes = nullptr;        // traversal nodes: 16 floats per internal node
+    bool has_bvh = false;
+    float bbox[6] = {0, 0, 0, 0, 0, 0};
+};
+
+hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, const inv_camera& cam, float* clip4,
+                                float* color3);
+hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
+                           const float* translations, uint32_t ninst, float* A, float* B, float* C);
+hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out);
+hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out);
+hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint32_t* frame);
+// LBVH build over triA/B/C (reorders them into Morton order); scratch is allocated and freed inside.
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc);
+
+} // namespace inv

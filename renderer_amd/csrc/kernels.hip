@@ -1,0 +1,153 @@
+// HIP kernels for gfx950: vertex stage, primitive assembly, brute-force render and
+// tile de-interleave.  The LBVH build and the traversal render live in lbvh.hip and
+// traverse.hip.
+#include "internal.h"
+#include "rt_core.h"
+
+namespace inv {
+
+// ---------------------------------------------------------------------------------------------
+// vertexShader (src/shader.slang:22-29): clip = P*(V*(M*(pos,1))) as three successive products.
+// ---------------------------------------------------------------------------------------------
+struct Mats {
+    float m[16], v[16], p[16];
+};
+
+__device__ __forceinline__ float4 mat_vec(const float* m, float4 x) {
+    float4 r;
+    r.x = ((m[0] * x.x + m[4] * x.y) + m[8] * x.z) + m[12] * x.w;
+    r.y = ((m[1] * x.x + m[5] * x.y) + m[9] * x.z) + m[13] * x.w;
+    r.z = ((m[2] * x.x + m[6] * x.y) + m[10] * x.z) + m[14] * x.w;
+    r.w = ((m[3] * x.x + m[7] * x.y) + m[11] * x.z) + m[15] * x.w;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_vertex_shader(const float4* __restrict__ xyzw, uint32_t nv, Mats mats,
+                                                       float4* __restrict__ clip, float* __restrict__ color3) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    float4 p = xyzw[i];
+    p.w = 1.0f; // float4(input.pos, 1.0f): lane 3 of the vertex buffer is ignored
+    float4 c = mat_vec(mats.p, mat_vec(mats.v, mat_vec(mats.m, p)));
+    if (clip) clip[i] = c;
+    if (color3) {
+        color3[3 * (size_t)i + 0] = 1.0f;
+        color3[3 * (size_t)i + 1] = 1.0f;
+        color3[3 * (size_t)i + 2] = p.z * 10.0f;
+    }
+}
+
+hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, const inv_camera& cam, float* clip4,
+                                float* color3) {
+    if (nv == 0) return hipSuccess;
+    Mats mats;
+    for (int i = 0; i < 16; i++) mats.m[i] = cam.model[i], mats.v[i] = cam.view[i], mats.p[i] = cam.proj[i];
+    hipLaunchKernelGGL(k_vertex_shader, dim3((nv + 255) / 256), dim3(256), 0, s, (const float4*)xyzw, nv, mats,
+                       (float4*)clip4, color3);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Primitive assembly (VK_PRIMITIVE_TOPOLOGY_TRIANGLE_LIST, src/invert.cpp:1307-1310): triangle k
+// of instance j = vertices idx[3k..3k+2] (+ translation j) -> A/B/C records, primitive id
+// j*base_ntri + k.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(const float4* __restrict__ xyzw, const uint32_t* __restrict__ idx,
+                                                  uint32_t base_ntri, const float* __restrict__ translations,
+                                                  uint32_t ninst, float4* __restrict__ A, float4* __restrict__ B,
+                                                  float4* __restrict__ C) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = (uint64_t)base_ntri * ninst;
+    if (g >= total) return;
+    uint32_t inst = (uint32_t)(g / base_ntri), k = (uint32_t)(g % base_ntri);
+    float4 a = xyzw[idx[3 * (size_t)k + 0]];
+    float4 b = xyzw[idx[3 * (size_t)k + 1]];
+    float4 c = xyzw[idx[3 * (size_t)k + 2]];
+    if (translations) {
+        float tx = translations[3 * (size_t)inst + 0], ty = translations[3 * (size_t)inst + 1],
+              tz = translations[3 * (size_t)inst + 2];
+        a.x = a.x + tx, a.y = a.y + ty, a.z = a.z + tz;
+        b.x = b.x + tx, b.y = b.y + ty, b.z = b.z + tz;
+        c.x = c.x + tx, c.y = c.y + ty, c.z = c.z + tz;
+    }
+    A[g] = make_float4(a.x, a.y, a.z, __uint_as_float((uint32_t)g));
+    B[g] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.z);
+    C[g] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, c.z);
+}
+
+hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
+                           const float* translations, uint32_t ninst, float* A, float* B, float* C) {
+    (void)nv;
+    uint64_t total = (uint64_t)base_ntri * ninst;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)xyzw, idx,
+                       base_ntri, translations, ninst, (float4*)A, (float4*)B, (float4*)C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Brute force: one lane per pixel, every triangle tested (INV_BRUTE_FORCE).  The triangle index is
+// wave-uniform, so the records come in through scalar loads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_pixel(const FrameK& f, const Outputs& out, uint64_t i, const Hit& first,
+                                            float r, float g, float b) {
+    if (out.depth) out.depth[i] = __uint_as_float((uint32_t)(first.key >> 32));
+    if (out.primid) out.primid[i] = (uint32_t)first.key;
+    if (out.color) ((uint32_t*)out.color)[i] = pack_pixel(f.flags, r, g, b);
+}
+
+__global__ __launch_bounds__(256) void k_render_brute(FrameK f, const float4* __restrict__ TA,
+                                                      const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                                      uint32_t ntri, Outputs out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.npix) return;
+    uint32_t px, py;
+    if (!work_to_pixel(f, i, px, py)) return;
+    uint32_t pix = py * f.w + px;
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    Hit first = miss_hit();
+    for (uint32_t s = 0; s < f.spp; s++) {
+        float sx, sy;
+        sample_offset(pix, s, f.seed, sx, sy);
+        Ray ray = make_ray(f, px, py, sx, sy);
+        Hit best = miss_hit();
+        for (uint32_t k = 0; k < ntri; k++) mt_test(f, ray, TA[k], TB[k], TC[k], k, best);
+        if (s == 0) first = best;
+        float r, g, b;
+        shade_sample(f, best, TA, TB, TC, r, g, b);
+        sr = sr + r, sg = sg + g, sb = sb + b;
+    }
+    float n = (float)f.spp;
+    store_pixel(f, out, i, first, sr / n, sg / n, sb / n);
+}
+
+hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out) {
+    if (f.npix == 0) return hipSuccess;
+    uint64_t blocks = (f.npix + 255) / 256;
+    hipLaunchKernelGGL(k_render_brute, dim3((unsigned)blocks), dim3(256), 0, s, f, (const float4*)sc.triA,
+                       (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rank 0 after the gather: tile-major buffers of all ranks -> one row-major frame.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_deinterleave(FrameK f, const uint32_t* __restrict__ gathered,
+                                                      uint32_t* __restrict__ frame) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)f.w * f.h) return;
+    uint32_t px = (uint32_t)(i % f.w), py = (uint32_t)(i / f.w);
+    uint32_t id = (py / f.tile) * f.tiles_x + px / f.tile;
+    uint32_t r = id % f.nranks, slot = id / f.nranks;
+    uint64_t src = ((uint64_t)r * f.slots + slot) * (f.tile * f.tile) + (py % f.tile) * f.tile + px % f.tile;
+    frame[i] = gathered[src];
+}
+
+hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint32_t* frame) {
+    uint64_t n = (uint64_t)f.w * f.h;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f, gathered, frame);
+    return hipGetLastError();
+}
+
+} // namespace inv

@@ -1,0 +1,184 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle and the committed goldens.
+
+Bar: bit-exact primitive id, depth bits and colour bytes (integer / byte work, no tolerance).
+"""
+import numpy as np
+import pytest
+
+import common
+import objfmt
+import renderer_amd as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bunny_scene(gpu_ctx, bunny_path):
+    mesh = R.Mesh.load_obj(bunny_path)
+    scene = R.Scene(gpu_ctx, mesh)
+    yield scene
+    scene.close()
+
+
+def _oracle_params(oracle, prm):
+    return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays, prm.flags & ~R.BRUTE_FORCE, prm.seed)
+
+
+def test_vertex_stage_matches_oracle(oracle, bunny_scene, bunny_mesh):
+    cam = R.camera_reference(1920, 1080)
+    clip, col = bunny_scene.vertex_shader(cam)
+    oclip, ocol = oracle.vertex_shader(bunny_mesh[0], oracle.camera_reference(1920, 1080))
+    assert np.array_equal(clip.view(np.uint32), oclip.view(np.uint32))
+    assert np.array_equal(col.view(np.uint32), ocol.view(np.uint32))
+
+
+@pytest.mark.parametrize("flags", [0, R.BRUTE_FORCE])
+def test_config1_512_against_golden(bunny_scene, flags):
+    got = bunny_scene.render(R.camera_reference(512, 512), R.make_params(512, 512, flags=flags))
+    common.assert_frames_equal(got, common.golden_frame("bunny_512"), "config 1")
+    assert int((got[2] != 0xFFFFFFFF).sum()) == 5651
+
+
+def test_config2_1080_against_golden(bunny_scene):
+    got = bunny_scene.render(R.camera_reference(1920, 1080), R.make_params(1920, 1080))
+    common.assert_frames_equal(got, common.golden_frame("bunny_1080_rect"), "config 2 (parity mode)")
+    assert int((got[2] != 0xFFFFFFFF).sum()) == 25139
+
+
+@pytest.mark.parametrize("flags", [R.LAMBERT, R.INVERT, R.LAMBERT | R.INVERT, R.LAMBERT | R.INVERT | R.RGBA])
+@pytest.mark.parametrize("brute", [0, R.BRUTE_FORCE])
+def test_shading_modes_against_oracle(oracle, bunny_scene, bunny_mesh, flags, brute):
+    w, h = 640, 360
+    prm = R.make_params(w, h, flags=flags | brute)
+    got = bunny_scene.render(R.camera_reference(w, h), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "flags=%d" % flags)
+
+
+def test_config2_timed_mode_1080_against_oracle(oracle, bunny_scene, bunny_mesh):
+    """1080p primary + Lambert + invert: the workload bench.py times."""
+    prm = R.make_params(1920, 1080, flags=R.LAMBERT | R.INVERT)
+    got = bunny_scene.render(R.camera_reference(1920, 1080), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(1920, 1080), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "config 2 (Lambert + invert)")
+
+
+@pytest.mark.parametrize("brute", [0, R.BRUTE_FORCE])
+def test_jittered_samples_against_oracle(oracle, bunny_scene, bunny_mesh, brute):
+    w, h = 320, 240
+    prm = R.make_params(w, h, spp=4, seed=11, flags=R.LAMBERT | brute)
+    got = bunny_scene.render(R.camera_reference(w, h), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "spp=4")
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (64, 64), (129, 65), (1000, 3)])
+def test_odd_extents(oracle, bunny_scene, bunny_mesh, size):
+    w, h = size
+    prm = R.make_params(w, h)
+    got = bunny_scene.render(R.camera_reference(w, h), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "%dx%d" % size)
+
+
+def test_moved_camera(oracle, bunny_scene, bunny_mesh):
+    """A camera other than the reference's: closer, off-axis, rotated model matrix."""
+    w, h = 400, 300
+    cam = R.camera_reference(w, h)
+    view = np.array(cam.view, np.float32).reshape(4, 4)
+    view[3, :3] = [0.03, 0.11, -0.35]  # translation column
+    c, s = np.float32(np.cos(0.5)), np.float32(np.sin(0.5))
+    model = np.eye(4, dtype=np.float32)
+    model[0, 0], model[0, 2], model[2, 0], model[2, 2] = c, -s, s, c
+    cam.view[:] = view.reshape(-1).tolist()
+    cam.model[:] = model.reshape(-1).tolist()
+    ocam = oracle.Camera.from_buffer_copy(bytes(cam))
+    for flags in (0, R.LAMBERT):
+        prm = R.make_params(w, h, flags=flags)
+        got = bunny_scene.render(cam, prm)
+        want = oracle.render_bvh(*bunny_mesh, ocam, _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "moved camera")
+        assert (got[2] != 0xFFFFFFFF).sum() > 5000
+
+
+def test_random_soup_and_degenerate_triangles(oracle, gpu_ctx):
+    """Unsorted overlapping triangles (depth test and tie-break matter), plus zero-area and repeated faces."""
+    xyz, faces = objfmt.random_soup(600, seed=5)
+    faces = np.concatenate([faces, faces[:50], np.array([[0, 0, 1], [2, 2, 2]], np.uint32)])  # duplicates: lower id wins
+    text = objfmt.from_floats(xyz, faces).text()
+    mesh = R.Mesh.parse_obj(text)
+    scene = R.Scene(gpu_ctx, mesh)
+    oxyzw, oidx = oracle.parse_obj(text)
+    w, h = 300, 300
+    for flags in (0, R.BRUTE_FORCE, R.LAMBERT):
+        prm = R.make_params(w, h, flags=flags)
+        got = scene.render(R.camera_reference(w, h), prm)
+        want = oracle.render_bruteforce(oxyzw, oidx, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "soup flags=%d" % flags)
+    assert (got[2] != 0xFFFFFFFF).sum() > 2000
+    scene.close()
+
+
+def test_tiny_scenes(oracle, gpu_ctx):
+    """0, 1 and 2 triangles (no LBVH below 2)."""
+    tri = np.array([[-0.05, 0.05, 0.0], [0.05, 0.05, 0.0], [0.0, 0.15, 0.02],
+                    [-0.02, 0.08, 0.03], [0.0, 0.12, 0.03], [0.02, 0.08, 0.03]])
+    for nf in (0, 1, 2):
+        faces = np.array([[0, 1, 2], [3, 5, 4]], np.uint32)[:nf]
+        text = objfmt.from_floats(tri, faces).text()
+        scene = R.Scene(gpu_ctx, R.Mesh.parse_obj(text))
+        oxyzw, oidx = oracle.parse_obj(text)
+        prm = R.make_params(128, 128)
+        got = scene.render(R.camera_reference(128, 128), prm)
+        want = oracle.render_bruteforce(oxyzw, oidx, oracle.camera_reference(128, 128), _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "%d triangles" % nf)
+        scene.close()
+
+
+@pytest.mark.parametrize("nranks,tile", [(2, 64), (3, 32), (8, 64)])
+def test_tile_sharding_and_deinterleave(bunny_scene, gpu_ctx, nranks, tile):
+    """Every rank's tile slots, put back together, equal the single-rank frame (no data-path exchange)."""
+    import torch
+    w, h = 1920, 1080
+    cam = R.camera_reference(w, h)
+    flags = R.LAMBERT | R.INVERT
+    full = bunny_scene.render(cam, R.make_params(w, h, flags=flags))
+    parts = [bunny_scene.render(cam, R.make_params(w, h, flags=flags, tile=tile, rank=r, nranks=nranks))
+             for r in range(nranks)]
+    for k in range(3):
+        frame = common.slots_to_frame([p[k] for p in parts], w, h, tile, nranks)
+        assert np.array_equal(frame, full[k])
+    # device de-interleave kernel (what rank 0 runs after the gather)
+    gathered = torch.from_numpy(np.concatenate([p[2].reshape(-1) for p in parts]).view(np.int32)).cuda()
+    out = torch.empty(h * w, dtype=torch.int32, device="cuda")
+    gpu_ctx.deinterleave(R.make_params(w, h, tile=tile, nranks=nranks), gathered.data_ptr(), out.data_ptr())
+    gpu_ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full[2])
+
+
+def test_device_outputs_on_torch_stream(bunny_scene, bunny_path):
+    """Device-pointer outputs on the caller's stream (the path bench.py times)."""
+    import torch
+    torch.cuda.set_device(0)
+    ctx = R.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    scene = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
+    w, h = 1920, 1080
+    color = torch.empty(h, w, 4, dtype=torch.uint8, device="cuda")
+    depth = torch.empty(h, w, dtype=torch.float32, device="cuda")
+    primid = torch.empty(h, w, dtype=torch.int32, device="cuda")
+    scene.render_device(R.camera_reference(w, h), R.make_params(w, h), color.data_ptr(), depth.data_ptr(), primid.data_ptr())
+    torch.cuda.synchronize()
+    got = (color.cpu().numpy(), depth.cpu().numpy(), primid.cpu().numpy().view(np.uint32))
+    common.assert_frames_equal(got, common.golden_frame("bunny_1080_rect"), "device outputs")
+    scene.close()
+    ctx.close()
+
+
+def test_errors(bunny_scene):
+    cam = R.camera_reference(64, 64)
+    with pytest.raises(R.InvertError):
+        bunny_scene.render(cam, R.make_params(64, 64, ao_rays=1 << 30, flags=0, tile=12))
+    cam.proj[1] = 0.5  # not a GLM-style perspective
+    with pytest.raises(R.InvertError) as e:
+        bunny_scene.render(cam, R.make_params(64, 64))
+    assert e.value.code == R.api.ERR_UNSUPPORTED

@@ -1,0 +1,229 @@
+"""CPU tests: the oracle against the facts that pin it.
+
+The reference has no tests, goldens or known-answer vectors (parity unpinned), so
+the pins are (a) facts about res/bunny.obj and the reference's literals that can be
+derived independently of the oracle's code, and (b) this repo's committed goldens.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import common
+import objfmt
+
+
+def test_bunny_text_regenerates_byte_for_byte():
+    text = objfmt.bunny().text()
+    assert len(text) == 198443
+    assert hashlib.sha256(text).hexdigest() == objfmt.bunny_sha256()
+    assert objfmt.bunny_sha256().startswith("c93e4a6f") and objfmt.bunny_sha256().endswith("0d55ef")
+
+
+def test_loader_counts_and_first_vertices(bunny_mesh):
+    xyzw, idx = bunny_mesh
+    assert xyzw.shape == (2503, 4) and idx.size == 14904  # res/bunny.obj:2-3, src/invert.cpp:77-79
+    assert idx.min() == 0 and idx.max() == 2502 and np.unique(idx).size == 2503
+    want = [("-0x1.befaa6p-9", "0x1.0ae4fep-3", "0x1.646c70p-6"),
+            ("-0x1.4eb8c0p-4", "0x1.3852aep-3", "0x1.e5e2a8p-6"),
+            ("-0x1.f46ca4p-6", "0x1.ff181ep-4", "0x1.1fec58p-10")]
+    for i, row in enumerate(want):
+        assert [float(v) for v in xyzw[i, :3]] == [float.fromhex(s) for s in row]
+
+
+def test_loader_arithmetic_is_not_strtof(bunny_mesh):
+    """src/invert.cpp:139-152 rounds differently from a correctly rounded parse on 2844 of 7509 coordinates."""
+    xyzw, _ = bunny_mesh
+    lines = [ln for ln in objfmt.bunny().text().decode().splitlines() if ln.startswith("v ")]
+    exact = np.array([[np.float32(float(t)) for t in ln.split()[1:]] for ln in lines], np.float32)
+    ulp = np.abs(xyzw[:, :3].view(np.int32).astype(np.int64) - exact.view(np.int32))
+    assert int((ulp != 0).sum()) == 2844 and int(ulp.max()) == 3
+    # 10^-3 by repeated division is one ulp below the correctly rounded constant
+    n = np.float32(1.0)
+    for _ in range(3):
+        n = np.float32(n / np.float32(10.0))
+    assert float(n).hex() == "0x1.0624dc0000000p-10"
+
+
+def test_loader_restatement_in_numpy(bunny_mesh):
+    """Independent numpy float32 restatement of src/invert.cpp:139-152 from the decimal fields."""
+    xyzw, idx = bunny_mesh
+    fo = objfmt.bunny()
+    whole = (fo.mant // 10_000_000).astype(np.float32)
+    frac = (fo.mant % 10_000_000).astype(np.float32)
+    norm = np.ones(fo.mant.shape, np.float32)
+    for step in range(int(fo.expo.max())):
+        active = fo.expo > step
+        norm = np.where(active & fo.eneg, (norm / np.float32(10.0)).astype(np.float32), norm)
+        norm = np.where(active & ~fo.eneg, (norm * np.float32(10.0)).astype(np.float32), norm)
+    val = ((whole + (frac / np.float32(10000000.0)).astype(np.float32)).astype(np.float32) * norm).astype(np.float32)
+    val = (val * np.where(fo.neg, np.float32(-1.0), np.float32(1.0))).astype(np.float32)
+    assert np.array_equal(val.view(np.uint32), xyzw[:, :3].view(np.uint32))
+    assert np.array_equal(idx.reshape(-1, 3), fo.faces - 1)
+
+
+def test_loader_pins(bunny_mesh):
+    xyzw, idx = bunny_mesh
+    p = common.pins()
+    assert hashlib.sha256(np.ascontiguousarray(xyzw[:, :3]).tobytes()).hexdigest() == p["vertices_sha256"]
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == p["indices_sha256"]
+    assert np.allclose(xyzw[:, :3].min(0), [-0.09438042, 0.0333099, -0.06167917], atol=1e-8)
+    assert np.allclose(xyzw[:, :3].max(0), [0.0607788, 0.18699603, 0.05871464], atol=1e-8)
+
+
+def test_mesh_topology(bunny_mesh):
+    xyzw, idx = bunny_mesh
+    f = idx.reshape(-1, 3).astype(np.int64)
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    uniq, counts = np.unique(e, axis=0, return_counts=True)
+    assert len(uniq) == 7473 and int((counts == 1).sum()) == 42 and int((counts > 2).sum()) == 0
+    v = xyzw[:, :3].astype(np.float64)
+    vol = np.einsum("ij,ij->i", v[f[:, 0]], np.cross(v[f[:, 1]], v[f[:, 2]])).sum() / 6.0
+    assert abs(vol - 7.63e-4) < 2e-6  # outward CCW winding
+
+
+def test_camera_matches_literals(oracle):
+    cam = oracle.camera_reference(1920, 1080)
+    view = np.array(cam.view, np.float32).reshape(4, 4)  # [col][row]
+    s = np.float32(np.sin(np.float64(np.float32(180.0) * np.float32(0.017453292519943295))))
+    assert float(s).hex() == "-0x1.777a5c0000000p-24"  # sin(pi_f32) != 0 leaks into the view matrix
+    assert view[0, 0] == -1 and view[1, 1] == -1 and view[2, 2] == 1 and view[3, 2] == -1 and view[3, 3] == 1
+    assert view[0, 1] == s and view[1, 0] == -s
+    proj = np.array(cam.proj, np.float32).reshape(4, 4)
+    t = np.tan(np.float64(np.float32(np.float32(45.0) * np.float32(0.017453292519943295)) / np.float32(2.0)))
+    th = np.float32(t)
+    assert proj[1, 1] == np.float32(1.0) / th
+    assert proj[0, 0] == np.float32(1.0) / (np.float32(np.float32(1920.0) / np.float32(1080.0)) * th)
+    assert proj[2, 2] == np.float32(10.0) / (np.float32(0.1) - np.float32(10.0)) and proj[2, 3] == -1
+    assert proj[3, 2] == -(np.float32(10.0) * np.float32(0.1)) / (np.float32(10.0) - np.float32(0.1))
+    assert list(cam.cam_angle) == [0.0, 0.0, -1.0]  # src/invert.cpp:633
+
+
+@pytest.mark.parametrize("size", ["512x512", "1920x1080", "3840x2160"])
+def test_camera_pins(oracle, bunny_mesh, size):
+    w, h = [int(v) for v in size.split("x")]
+    cam = oracle.camera_reference(w, h)
+    p = common.pins()["cameras"][size]
+    for name in ("model", "view", "proj", "cam_angle"):
+        assert np.array_equal(np.array(getattr(cam, name), np.float32).view(np.uint32), common.unhex(p[name]).view(np.uint32))
+    frame = oracle.frame_setup(bunny_mesh[0], cam)
+    assert np.array_equal(frame.view(np.uint32), common.unhex(common.pins()["frames"][size]).view(np.uint32))
+
+
+def test_vertex_shader_matches_numpy(oracle, bunny_mesh):
+    xyzw, _ = bunny_mesh
+    cam = oracle.camera_reference(1920, 1080)
+    clip, col = oracle.vertex_shader(xyzw, cam)
+    p = xyzw.copy()
+    p[:, 3] = 1.0
+
+    def mv(m, v):  # column-major, left-to-right float32 sum (src/shader.slang:25)
+        m = np.array(m, np.float32).reshape(4, 4)
+        out = np.zeros_like(v)
+        for r in range(4):
+            acc = (m[0, r] * v[:, 0]).astype(np.float32)
+            for c in range(1, 4):
+                acc = (acc + (m[c, r] * v[:, c]).astype(np.float32)).astype(np.float32)
+            out[:, r] = acc
+        return out
+
+    want = mv(cam.proj, mv(cam.view, mv(cam.model, p)))
+    assert np.array_equal(want.view(np.uint32), clip.view(np.uint32))
+    assert np.array_equal(col[:, 2], (xyzw[:, 2] * np.float32(10.0)).astype(np.float32)) and (col[:, :2] == 1).all()
+    zv = -clip[:, 3]
+    assert zv.min() > -1.0625 and zv.max() < -0.94  # no clipping against near 0.1 / far 10
+
+
+@pytest.mark.parametrize("size,covered", [((512, 512), 5651), ((1920, 1080), 25139)])
+def test_rasteriser_facts(oracle, bunny_mesh, size, covered):
+    """A3+A4 as a double-precision rasteriser: 2565 front faces, pixel counts, screen rectangle."""
+    xyzw, idx = bunny_mesh
+    cam = oracle.camera_reference(*size)
+    depth, primid, nfront = oracle.raster(xyzw, idx, cam, *size)
+    hit = primid != 0xFFFFFFFF
+    assert nfront == 2565 and int(hit.sum()) == covered
+    assert 0.90279 <= depth[hit].min() and depth[hit].max() <= 0.91496
+    if size == (1920, 1080):
+        ys, xs = np.nonzero(hit)
+        assert (xs.min(), xs.max(), ys.min(), ys.max()) == (880, 1085, 301, 496)
+
+
+def test_ray_casting_reproduces_the_rasteriser(oracle, bunny_mesh):
+    """Primary rays + Moller-Trumbore pick the same primitive as the rasteriser at every pixel of config 1."""
+    xyzw, idx = bunny_mesh
+    cam = oracle.camera_reference(512, 512)
+    color, depth, primid = oracle.render_bruteforce(xyzw, idx, cam, oracle.make_params(512, 512))
+    rdepth, rprim, _ = oracle.raster(xyzw, idx, cam, 512, 512)
+    assert int((primid != rprim).sum()) <= 2  # pixel centres within rounding of an edge may differ
+    same = (primid == rprim) & (primid != 0xFFFFFFFF)
+    assert np.abs(depth[same].astype(np.float64) - rdepth[same]).max() < 8 * 2.0 ** -24
+    hit = primid != 0xFFFFFFFF
+    assert (color[..., 1][hit] == 255).all() and (color[..., 2][hit] == 255).all() and (color[..., 3] == 255).all()
+    assert color[..., 0][hit].max() == 201 and (color[~hit] == [0, 0, 0, 255]).all()
+    z10 = np.clip(10.0 * xyzw[:, 2].astype(np.float64), 0, 1)
+    assert color[..., 0][hit].max() <= oracle.srgb8(z10.max())
+
+
+@pytest.mark.parametrize("name", ["bunny_512", "bunny_1080_rect"])
+def test_oracle_reproduces_goldens(oracle, bunny_mesh, name):
+    xyzw, idx = bunny_mesh
+    want = common.golden_frame(name)
+    h, w = want[1].shape
+    cam = oracle.camera_reference(w, h)
+    got = oracle.render_bvh(xyzw, idx, cam, oracle.make_params(w, h))
+    common.assert_frames_equal(got, want, name)
+    p = common.pins()[name]
+    assert int((got[2] != 0xFFFFFFFF).sum()) == p["hits"]
+    assert hashlib.sha256(got[2].tobytes()).hexdigest() == p["primid_sha256"]
+    assert hashlib.sha256(got[1].tobytes()).hexdigest() == p["depth_sha256"]
+    assert hashlib.sha256(got[0].tobytes()).hexdigest() == p["color_sha256"]
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 7])
+def test_bvh_oracle_equals_brute_force(oracle, bunny_mesh, flags):
+    xyzw, idx = bunny_mesh
+    cam = oracle.camera_reference(256, 192)
+    prm = oracle.make_params(256, 192, flags=flags)
+    common.assert_frames_equal(oracle.render_bvh(xyzw, idx, cam, prm), oracle.render_bruteforce(xyzw, idx, cam, prm))
+
+
+def test_bvh_oracle_equals_brute_force_jittered(oracle, bunny_mesh):
+    xyzw, idx = bunny_mesh
+    cam = oracle.camera_reference(160, 120)
+    prm = oracle.make_params(160, 120, spp=4, seed=7, flags=1)
+    common.assert_frames_equal(oracle.render_bvh(xyzw, idx, cam, prm), oracle.render_bruteforce(xyzw, idx, cam, prm))
+
+
+def test_bvh_oracle_on_random_soup(oracle):
+    xyz, faces = objfmt.random_soup(700, seed=3)
+    xyzw, idx = oracle.parse_obj(objfmt.from_floats(xyz, faces).text())
+    cam = oracle.camera_reference(200, 200)
+    prm = oracle.make_params(200, 200)
+    a = oracle.render_bvh(xyzw, idx, cam, prm)
+    b = oracle.render_bruteforce(xyzw, idx, cam, prm)
+    common.assert_frames_equal(a, b)
+    assert (a[2] != 0xFFFFFFFF).sum() > 1000
+
+
+def test_srgb_table(oracle):
+    """Thresholds against a float64 evaluation of the sRGB OETF (src/invert.cpp:519 stores B8G8R8A8_SRGB)."""
+    t = np.load(common.GOLDEN + "/srgb_thresholds.npy")
+
+    def enc(x):
+        x = np.float64(x)
+        s = 12.92 * x if x <= 0.0031308 else 1.055 * x ** (1 / 2.4) - 0.055
+        return int(np.floor(255.0 * s + 0.5))
+
+    for k in range(1, 256):
+        assert enc(t[k]) == k and enc(np.nextafter(t[k], np.float32(-1))) == k - 1
+        assert oracle.srgb8(t[k]) == k and oracle.srgb8(np.nextafter(t[k], np.float32(-1))) == k - 1
+    assert oracle.srgb8(-1.0) == 0 and oracle.srgb8(float("nan")) == 0 and oracle.srgb8(2.0) == 255
+    assert oracle.srgb8(0.0) == 0 and oracle.srgb8(1.0) == 255
+
+
+def test_sample_offsets(oracle):
+    assert oracle.sample_offset(12345, 0, 99) == (0.5, 0.5)
+    pts = np.array([oracle.sample_offset(p, s, 1) for p in range(64) for s in range(1, 17)])
+    assert pts.min() >= 0.0 and pts.max() < 1.0
+    assert abs(pts.mean() - 0.5) < 0.03 and len(np.unique(pts[:, 0])) > 1000
+    assert oracle.sample_offset(5, 3, 1) != oracle.sample_offset(5, 3, 2)
