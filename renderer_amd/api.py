@@ -62,6 +62,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `make -C renderer_amd/csrc` (hipcc, gfx950); "
                           "there is no CPU fallback" % LIB_PATH)
+    # torch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Loading it first makes this library bind
+    # to that copy; two HIP runtimes in one process cannot both open the GPU.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, u32p, u64p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.inv_last_error.restype = C.c_char_p

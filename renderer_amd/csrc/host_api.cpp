@@ -64,7 +64,7 @@ void dfree(T*& p) {
 
 void free_device_scene(DeviceScene& d) {
     dfree(d.xyzw), dfree(d.idx), dfree(d.triA), dfree(d.triB), dfree(d.triC);
-    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.box), dfree(d.nodes);
+    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.nodes);
 }
 
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).
@@ -80,7 +80,7 @@ int fill_layout(const inv_params& p, FrameK* f) {
     f->nranks = p.nranks ? p.nranks : 1u;
     f->rank = p.rank;
     if (f->rank >= f->nranks) return fail(INV_ERR_ARG, "params: rank must be below nranks");
-    if (f->tile > 1024u || (f->tile & 7u)) return fail(INV_ERR_ARG, "params: tile must be a multiple of 8, at most 1024");
+    if (f->tile > 1024u || (f->tile & 15u)) return fail(INV_ERR_ARG, "params: tile must be a multiple of 16, at most 1024");
     f->tiles_x = (p.width + f->tile - 1) / f->tile;
     uint32_t tiles_y = (p.height + f->tile - 1) / f->tile;
     f->ntiles = f->tiles_x * tiles_y;
@@ -315,7 +315,11 @@ int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uin
     if (child) HIP_TRY(hipMemcpy(child, d.child, (n - 1) * 8, hipMemcpyDeviceToHost));
     if (parent) HIP_TRY(hipMemcpy(parent, d.parent, (n - 1) * 4, hipMemcpyDeviceToHost));
     if (leaf_parent) HIP_TRY(hipMemcpy(leaf_parent, d.leaf_parent, n * 4, hipMemcpyDeviceToHost));
-    if (box) HIP_TRY(hipMemcpy(box, d.box, (n - 1) * 48, hipMemcpyDeviceToHost));
+    if (box) {
+        std::vector<float> nodes((n - 1) * 16);
+        HIP_TRY(hipMemcpy(nodes.data(), d.nodes, (n - 1) * 64, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i + 1 < n; i++) std::memcpy(box + 12 * i, nodes.data() + 16 * i, 48);
+    }
     return INV_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -37,9 +38,9 @@ struct DeviceScene {
     uint32_t* child = nullptr;     // 2*(ntri-1)
     uint32_t* parent = nullptr;    // ntri-1
     uint32_t* leaf_parent = nullptr; // ntri
-    float* box = nullptr;          // 12*(ntri-1)
-    float* nodes = nullptr;        // traversal nodes: 16 floats per internal node
+    float* nodes = nullptr;        // 16 floats per internal node: two child boxes, two child refs, height
     bool has_bvh = false;
+    uint32_t height = 0;           // height of the root (a node over two leaves has height 1)
     float bbox[6] = {0, 0, 0, 0, 0, 0};
 };
 

@@ -1,12 +1,455 @@
-// LBVH build (placeholder until the GPU build lands): scenes render through the brute-force kernel.
+// GPU LBVH build for gfx950: scene bounds -> 63-bit Morton codes of the triangle box centres ->
+// LDS-staged 8-bit radix sort (stable, so ties keep primitive order) -> Karras hierarchy ->
+// bottom-up refit with one arrival counter per internal node.
+//
+// The build is deterministic: every float that ends up in a node is a min/max of input floats,
+// the sort is stable and the hierarchy depends only on the sorted keys, so the tree is identical
+// on every rank and equal to a sequential restatement of the same steps.
 #include "internal.h"
+#include "rt_core.h"
 
 namespace inv {
-hipError_t build_lbvh(hipStream_t, DeviceScene& sc) {
+
+namespace {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;
+constexpr int kSortTile = kSortThreads * kSortItems; // keys per workgroup per pass
+
+// ------------------------------------------------------------------------------------------
+// 1. triangle boxes + scene bounds (two-stage min/max reduction, no float atomics)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_box(const float4& A, const float4& B, const float4& C, float lo[3], float hi[3]) {
+    float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
+    float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
+    lo[0] = fminf(A.x, fminf(bx, cx)), lo[1] = fminf(A.y, fminf(by, cy)), lo[2] = fminf(A.z, fminf(bz, cz));
+    hi[0] = fmaxf(A.x, fmaxf(bx, cx)), hi[1] = fmaxf(A.y, fmaxf(by, cy)), hi[2] = fmaxf(A.z, fmaxf(bz, cz));
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// partial[block][6] = lo xyz, hi xyz over the block's triangles (grid-stride)
+__global__ __launch_bounds__(256) void k_bounds_partial(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                        const float4* __restrict__ TC, uint32_t n,
+                                                        float* __restrict__ partial) {
+    __shared__ float red[4][6];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float l[3], h[3];
+        tri_box(TA[i], TB[i], TC[i], l, h);
+#pragma unroll
+        for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], l[a]), hi[a] = fmaxf(hi[a], h[a]);
+    }
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = wave_min(lo[a]), h = wave_max(hi[a]);
+        if (lane == 0) red[wave][a] = l, red[wave][3 + a] = h;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bounds_final(const float* __restrict__ partial, uint32_t nblocks,
+                                                     float* __restrict__ bbox) {
+    int lane = threadIdx.x;
+    for (int a = 0; a < 6; a++) {
+        float v = a < 3 ? INFINITY : -INFINITY;
+        for (uint32_t b = lane; b < nblocks; b += 64) v = a < 3 ? fminf(v, partial[b * 6 + a]) : fmaxf(v, partial[b * 6 + a]);
+        v = a < 3 ? wave_min(v) : wave_max(v);
+        if (lane == 0) bbox[a] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2. Morton keys: 21 bits per axis of the box centre, x in the highest interleaved position
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t expand21(uint32_t v) {
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t grid21(float c, float lo, float ext) {
+    float q = (ext > 0.0f) ? (c - lo) / ext : 0.0f;
+    float s = q * 2097152.0f;
+    if (!(s > 0.0f)) return 0u;
+    if (s >= 2097151.0f) return 2097151u;
+    return (uint32_t)s;
+}
+
+__global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                const float4* __restrict__ TC, uint32_t n,
+                                                const float* __restrict__ bbox, uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], hi[3];
+    tri_box(TA[i], TB[i], TC[i], lo, hi);
+    float ex = bbox[3] - bbox[0], ey = bbox[4] - bbox[1], ez = bbox[5] - bbox[2];
+    float cx = (lo[0] + hi[0]) * 0.5f, cy = (lo[1] + hi[1]) * 0.5f, cz = (lo[2] + hi[2]) * 0.5f;
+    keys[i] = (expand21(grid21(cx, bbox[0], ex)) << 2) | (expand21(grid21(cy, bbox[1], ey)) << 1) |
+              expand21(grid21(cz, bbox[2], ez));
+    vals[i] = i;
+}
+
+// ------------------------------------------------------------------------------------------
+// 3. radix sort, 8 bits per pass: per-tile digit histogram -> exclusive scan over
+//    (digit, tile) -> LDS-staged stable scatter
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+                                                            uint32_t ntiles, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * kSortTile;
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        uint32_t i = base + r * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of `len` counters by one workgroup of 1024 threads (chunk per thread)
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ counts, uint32_t len) {
+    __shared__ uint32_t part[1024];
+    uint32_t chunk = (len + 1023u) / 1024u;
+    uint32_t b = threadIdx.x * chunk, e = min(b + chunk, len);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += counts[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+    for (uint32_t i = b; i < e; i++) {
+        uint32_t c = counts[i];
+        counts[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* __restrict__ keys_in,
+                                                               const uint32_t* __restrict__ vals_in, uint32_t n,
+                                                               int shift, uint32_t ntiles,
+                                                               const uint32_t* __restrict__ offsets,
+                                                               uint64_t* __restrict__ keys_out,
+                                                               uint32_t* __restrict__ vals_out) {
+    __shared__ uint64_t s_key[kSortTile];
+    __shared__ uint32_t s_val[kSortTile];
+    __shared__ uint32_t s_wave[4][256]; // per-wave digit counts of the current round
+    __shared__ uint32_t s_run[256];     // digit counts of earlier rounds, later the tile-local digit start
+    __shared__ uint32_t s_goff[256];    // global start of (digit, this tile)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * kSortTile;
+    const uint32_t tile_n = min((uint32_t)kSortTile, n - base);
+    s_run[tid] = 0;
+    s_goff[tid] = offsets[tid * ntiles + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++) s_wave[w][tid] = 0;
+    __syncthreads();
+
+    uint64_t key[kSortItems];
+    uint32_t val[kSortItems], rank[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t j = r * kSortThreads + tid;
+        const bool valid = j < tile_n;
+        key[r] = valid ? keys_in[base + j] : ~0ull;
+        val[r] = valid ? vals_in[base + j] : 0u;
+        const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
+        // lanes of this wave holding the same digit
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (valid && before == 0) s_wave[wave][digit] = (uint32_t)__popcll(same);
+        __syncthreads();
+        uint32_t r0 = s_run[digit] + before;
+        for (uint32_t w = 0; w < wave; w++) r0 += s_wave[w][digit];
+        rank[r] = r0;
+        __syncthreads();
+        // thread d folds digit d's round total into the running count and clears the round
+        s_run[tid] += s_wave[0][tid] + s_wave[1][tid] + s_wave[2][tid] + s_wave[3][tid];
+        s_wave[0][tid] = 0, s_wave[1][tid] = 0, s_wave[2][tid] = 0, s_wave[3][tid] = 0;
+        __syncthreads();
+    }
+    // exclusive scan of the tile's digit counts -> tile-local digit start (s_run becomes the start)
+    {
+        uint32_t c = s_run[tid];
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= (unsigned)o) incl += v;
+        }
+        __shared__ uint32_t s_wsum[4];
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t prev = 0;
+        for (uint32_t w = 0; w < wave; w++) prev += s_wsum[w];
+        s_run[tid] = prev + incl - c;
+        __syncthreads();
+    }
+    // stage into LDS in digit order, then write runs out with consecutive lanes on consecutive addresses
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t j = r * kSortThreads + tid;
+        if (j < tile_n) {
+            const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t p = s_run[digit] + rank[r];
+            s_key[p] = key[r];
+            s_val[p] = val[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t j = r * kSortThreads + tid;
+        if (j < tile_n) {
+            const uint64_t k = s_key[j];
+            const uint32_t digit = (uint32_t)(k >> shift) & 255u;
+            const uint32_t g = s_goff[digit] + (j - s_run[digit]);
+            keys_out[g] = k;
+            vals_out[g] = s_val[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 4. gather the triangle records into sorted order
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_permute(const float4* __restrict__ A0, const float4* __restrict__ B0,
+                                                 const float4* __restrict__ C0, const uint32_t* __restrict__ order,
+                                                 uint32_t n, float4* __restrict__ A1, float4* __restrict__ B1,
+                                                 float4* __restrict__ C1) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = order[i];
+    A1[i] = A0[s], B1[i] = B0[s], C1[i] = C0[s];
+}
+
+// ------------------------------------------------------------------------------------------
+// 5. hierarchy: T. Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and
+//    k-d Trees", HPG 2012, section 4.  Keys are made unique by appending the sorted position.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ m, uint32_t n, int64_t i, int64_t j) {
+    if (j < 0 || j >= (int64_t)n) return -1;
+    uint64_t a = m[i], b = m[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+}
+
+__global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, uint32_t n,
+                                                uint32_t* __restrict__ child, uint32_t* __restrict__ parent,
+                                                uint32_t* __restrict__ leaf_parent) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n - 1) return;
+    if (i == 0) parent[0] = 0xFFFFFFFFu;
+    int d = (delta(m, n, i, i + 1) - delta(m, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(m, n, i, i - d);
+    int64_t lmax = 2;
+    while (delta(m, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int64_t l = 0;
+    for (int64_t t = lmax / 2; t >= 1; t /= 2)
+        if (delta(m, n, i, i + (l + t) * d) > dmin) l += t;
+    int64_t j = i + l * d;
+    int dnode = delta(m, n, i, j);
+    int64_t s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (delta(m, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int64_t gamma = i + s * d + (d < 0 ? d : 0);
+    int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    uint32_t c0, c1;
+    if (lo == gamma) {
+        c0 = (uint32_t)gamma | 0x80000000u;
+        leaf_parent[gamma] = (uint32_t)i;
+    } else {
+        c0 = (uint32_t)gamma;
+        parent[gamma] = (uint32_t)i;
+    }
+    if (hi == gamma + 1) {
+        c1 = (uint32_t)(gamma + 1) | 0x80000000u;
+        leaf_parent[gamma + 1] = (uint32_t)i;
+    } else {
+        c1 = (uint32_t)(gamma + 1);
+        parent[gamma + 1] = (uint32_t)i;
+    }
+    child[2 * i] = c0;
+    child[2 * i + 1] = c1;
+}
+
+// ------------------------------------------------------------------------------------------
+// 6. refit: one lane per leaf walks to the root; the second lane to arrive at a node owns it.
+//    Node i (16 floats): child0 lo xyz, hi xyz, child1 lo xyz, hi xyz, child0, child1,
+//    subtree height, unused.  union_box[i] (8 floats) carries the node's own box upwards.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                               const float4* __restrict__ TC, const float* union_box, float lo[3],
+                                               float hi[3], uint32_t& height) {
+    if (c & 0x80000000u) {
+        uint32_t k = c & 0x7FFFFFFFu;
+        tri_box(TA[k], TB[k], TC[k], lo, hi);
+        height = 0;
+    } else {
+        // written by another workgroup earlier in this launch: agent-scope loads that bypass the L1
+        const float* u = union_box + 8 * (size_t)c;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[a] = __hip_atomic_load(u + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hi[a] = __hip_atomic_load(u + 3 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        height = __float_as_uint(__hip_atomic_load(u + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_refit(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                               const float4* __restrict__ TC, uint32_t n,
+                                               const uint32_t* __restrict__ child, const uint32_t* __restrict__ parent,
+                                               const uint32_t* __restrict__ leaf_parent, uint32_t* __restrict__ arrive,
+                                               float* union_box, float* __restrict__ nodes) {
+    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    uint32_t node = leaf_parent[leaf];
+    // every lane ends at the root at the latest: the walk is bounded by the tree height
+    while (node != 0xFFFFFFFFu) {
+        uint32_t old = atomicAdd(&arrive[node], 1u); // device scope
+        if (old == 0) return;                        // the sibling subtree is not finished; its lane continues
+        __threadfence();                             // acquire: see what the first arrival published
+        uint32_t c0 = child[2 * (size_t)node], c1 = child[2 * (size_t)node + 1];
+        float l0[3], h0[3], l1[3], h1[3];
+        uint32_t ht0, ht1;
+        load_child_box(c0, TA, TB, TC, union_box, l0, h0, ht0);
+        load_child_box(c1, TA, TB, TC, union_box, l1, h1, ht1);
+        float* nd = nodes + 16 * (size_t)node;
+        uint32_t ht = 1u + (ht0 > ht1 ? ht0 : ht1);
+        nd[0] = l0[0], nd[1] = l0[1], nd[2] = l0[2], nd[3] = h0[0], nd[4] = h0[1], nd[5] = h0[2];
+        nd[6] = l1[0], nd[7] = l1[1], nd[8] = l1[2], nd[9] = h1[0], nd[10] = h1[1], nd[11] = h1[2];
+        nd[12] = __uint_as_float(c0), nd[13] = __uint_as_float(c1), nd[14] = __uint_as_float(ht), nd[15] = 0.0f;
+        float* u = union_box + 8 * (size_t)node;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            __hip_atomic_store(u + a, fminf(l0[a], l1[a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(u + 3 + a, fmaxf(h0[a], h1[a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(u + 6, __uint_as_float(ht), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence(); // release before announcing arrival at the parent
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        node = parent[node];
+    }
+}
+
+#define HIP_RET(expr)                     \
+    do {                                  \
+        hipError_t e_ = (expr);           \
+        if (e_ != hipSuccess) return e_;  \
+    } while (0)
+
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T** p, size_t bytes) {
+        hipError_t e = hipMalloc((void**)p, bytes ? bytes : 16);
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+} // namespace
+
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
+    const uint32_t n = sc.ntri;
     sc.has_bvh = false;
+    if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
+    Scratch tmp;
+    const uint32_t bounds_blocks = std::min<uint32_t>((n + 255) / 256, 1024);
+    const uint32_t ntiles = (n + kSortTile - 1) / kSortTile;
+    float *partial, *d_bbox, *union_box;
+    uint64_t* keys_alt;
+    uint32_t *vals_alt, *counts, *arrive;
+    float4 *A1, *B1, *C1;
+    HIP_RET(tmp.alloc(&partial, (size_t)bounds_blocks * 24));
+    HIP_RET(tmp.alloc(&d_bbox, 32));
+    HIP_RET(tmp.alloc(&keys_alt, (size_t)n * 8));
+    HIP_RET(tmp.alloc(&vals_alt, (size_t)n * 4));
+    HIP_RET(tmp.alloc(&counts, (size_t)ntiles * 256 * 4));
+    HIP_RET(tmp.alloc(&arrive, (size_t)(n - 1) * 4));
+    HIP_RET(tmp.alloc(&union_box, (size_t)(n - 1) * 32));
+    // persistent results
+    HIP_RET(hipMalloc((void**)&sc.morton, (size_t)n * 8));
+    HIP_RET(hipMalloc((void**)&sc.order, (size_t)n * 4));
+    HIP_RET(hipMalloc((void**)&sc.child, (size_t)(n - 1) * 8));
+    HIP_RET(hipMalloc((void**)&sc.parent, (size_t)(n - 1) * 4));
+    HIP_RET(hipMalloc((void**)&sc.leaf_parent, (size_t)n * 4));
+    HIP_RET(hipMalloc((void**)&sc.nodes, (size_t)(n - 1) * 64));
+    HIP_RET(hipMalloc((void**)&A1, (size_t)n * 16));
+    HIP_RET(hipMalloc((void**)&B1, (size_t)n * 16));
+    HIP_RET(hipMalloc((void**)&C1, (size_t)n * 16));
+
+    const float4 *A0 = (const float4*)sc.triA, *B0 = (const float4*)sc.triB, *C0 = (const float4*)sc.triC;
+    const dim3 blk(256), grid_n((n + 255) / 256);
+    hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_blocks), blk, 0, s, A0, B0, C0, n, partial);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, bounds_blocks, d_bbox);
+    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, A0, B0, C0, n, d_bbox, sc.morton, sc.order);
+    // 63 significant key bits -> 8 passes; an even number of passes leaves the result in sc.morton / sc.order
+    uint64_t* kin = sc.morton;
+    uint32_t* vin = sc.order;
+    uint64_t* kout = keys_alt;
+    uint32_t* vout = vals_alt;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, counts, ntiles * 256u);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(kSortThreads), 0, s, kin, vin, n, shift, ntiles, counts,
+                           kout, vout);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, A0, B0, C0, sc.order, n, A1, B1, C1);
+    hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent);
+    HIP_RET(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, s));
+    hipLaunchKernelGGL(k_refit, grid_n, blk, 0, s, (const float4*)A1, (const float4*)B1, (const float4*)C1, n, sc.child,
+                       sc.parent, sc.leaf_parent, arrive, union_box, sc.nodes);
+    HIP_RET(hipGetLastError());
+    HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
+    HIP_RET(hipMemcpyAsync(&sc.height, sc.nodes + 14, 4, hipMemcpyDeviceToHost, s)); // root height
+    HIP_RET(hipStreamSynchronize(s)); // scratch is freed on return
+    (void)hipFree(sc.triA), (void)hipFree(sc.triB), (void)hipFree(sc.triC);
+    sc.triA = (float*)A1, sc.triB = (float*)B1, sc.triC = (float*)C1;
+    sc.has_bvh = true;
     return hipSuccess;
 }
-hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out) {
-    return launch_render_brute(s, f, sc, out);
-}
+
 } // namespace inv

@@ -19,7 +19,7 @@ struct Ray {
 
 struct Hit {
     uint64_t key; // (depth bits << 32) | primitive id ; miss = (bits of 1.0f, 0xFFFFFFFF)
-    float un, vn, det;
+    float t, un, vn, det;
     uint32_t slot; // storage slot of the winning triangle (for the attribute fetch)
 };
 
@@ -105,7 +105,7 @@ __device__ __forceinline__ void mt_test(const FrameK& f, const Ray& r, const flo
     uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint64_t)__float_as_uint(A.w);
     if (key < best.key) { // depth LESS, lower primitive wins ties (src/invert.cpp:1384 + draw order)
         best.key = key;
-        best.un = un, best.vn = vn, best.det = det;
+        best.t = t, best.un = un, best.vn = vn, best.det = det;
         best.slot = slot;
     }
 }
@@ -113,7 +113,7 @@ __device__ __forceinline__ void mt_test(const FrameK& f, const Ray& r, const flo
 __device__ __forceinline__ Hit miss_hit() {
     Hit h;
     h.key = kMissKey;
-    h.un = 0.0f, h.vn = 0.0f, h.det = 1.0f;
+    h.t = INFINITY, h.un = 0.0f, h.vn = 0.0f, h.det = 1.0f;
     h.slot = 0;
     return h;
 }

@@ -177,8 +177,46 @@ def test_device_outputs_on_torch_stream(bunny_scene, bunny_path):
 def test_errors(bunny_scene):
     cam = R.camera_reference(64, 64)
     with pytest.raises(R.InvertError):
-        bunny_scene.render(cam, R.make_params(64, 64, ao_rays=1 << 30, flags=0, tile=12))
+        bunny_scene.render(cam, R.make_params(64, 64, tile=12))
     cam.proj[1] = 0.5  # not a GLM-style perspective
     with pytest.raises(R.InvertError) as e:
         bunny_scene.render(cam, R.make_params(64, 64))
     assert e.value.code == R.api.ERR_UNSUPPORTED
+
+
+def _check_lbvh(oracle, scene, xyzw, idx):
+    got = scene.read_lbvh()
+    want = oracle.lbvh_build(xyzw, idx)
+    assert np.array_equal(got["morton"], want["morton"]), "sorted Morton keys"
+    assert np.array_equal(got["order"], want["order"]), "sorted order (stable: ties keep primitive order)"
+    assert np.array_equal(got["child"], want["child"]), "Karras hierarchy"
+    assert np.array_equal(got["parent"], want["parent"])
+    assert np.array_equal(got["leaf_parent"], want["leaf_parent"])
+    assert np.array_equal(got["box"], want["box"]), "refitted child boxes"  # min/max of inputs: exact
+    n = len(want["order"])
+    assert sorted(got["order"].tolist()) == list(range(n))
+    assert (np.diff(got["morton"].astype(np.int64)) >= 0).all()
+
+
+def test_lbvh_structure_matches_the_sequential_restatement(oracle, bunny_scene, bunny_mesh):
+    ntri, nnodes, nbytes = bunny_scene.counts()
+    assert (ntri, nnodes) == (4968, 4967) and nbytes == 4968 * 48 + 4967 * 64
+    _check_lbvh(oracle, bunny_scene, *bunny_mesh)
+
+
+@pytest.mark.parametrize("ntri,seed", [(2, 0), (3, 1), (257, 2), (2048, 3), (2049, 4), (20000, 5)])
+def test_lbvh_structure_random(oracle, gpu_ctx, ntri, seed):
+    """Sizes around the sort tile (2048 keys) and duplicated triangles (equal Morton keys, index tie-break)."""
+    xyz, faces = objfmt.random_soup(ntri, seed=seed, size=0.004)
+    if ntri > 100:
+        faces[ntri // 2:ntri // 2 + 40] = faces[:40]  # 40 exact duplicates
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    idx = faces.reshape(-1).astype(np.uint32)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    _check_lbvh(oracle, scene, xyzw, idx)
+    prm = R.make_params(256, 256)
+    got = scene.render(R.camera_reference(256, 256), prm)
+    want = oracle.render_bvh(xyzw, idx, oracle.camera_reference(256, 256), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "%d triangles" % ntri)
+    scene.close()
