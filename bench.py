@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s on the 1080p bunny (primary rays + Lambert shade + invert post-pass).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One step = one frame of the workload rendered through the C ABI (include/invert.h) with every input
+(triangles, LBVH) and output buffer resident in HBM.  With N > 1 (launched by torch.distributed.run, one
+process per GPU) the frame's 64x64 screen tiles are dealt round-robin to the ranks, every rank renders its
+tiles, and the three attachments are gathered to rank 0 over RCCL and de-interleaved there; the same frame
+is rendered whatever N is, so scaling is "strong".
+
+Rank 0 prints one JSON line with the contract fields plus
+  roofline      -- the render kernel against the HBM roofline (algorithmic bytes = 12 B per pixel written +
+                   the scene read once), duration from HIP events around every launch of the timed region
+  cpu_baseline  -- the CPU oracle (a scalar C++ port of the same algorithm; the reference has no CPU path)
+                   timed on this host's cores on the same frame
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import objfmt  # noqa: E402
+import renderer_amd as R  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "bunny_1080p_primary_lambert_invert": dict(width=1920, height=1080, spp=1, flags=R.LAMBERT | R.INVERT),
+    # configs[2]: 4K, 16 jittered samples per pixel
+    "bunny_4k_16spp": dict(width=3840, height=2160, spp=16, flags=R.LAMBERT | R.INVERT),
+    # parity mode of configs[1]
+    "bunny_1080p_parity": dict(width=1920, height=1080, spp=1, flags=0),
+}
+
+
+def cpu_baseline(wl, budget_s=8.0):
+    """Time the CPU oracle on the same frame (bounded: whole frames until the budget is used)."""
+    from oracle import oracle as O
+
+    xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
+    w, h = wl["width"], wl["height"]
+    cam = O.camera_reference(w, h)
+    prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"])
+    cores = min(16, os.cpu_count() or 1)
+    O.render_bvh(xyzw, idx, cam, prm, nthreads=cores)  # warm
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        out = O.render_bvh(xyzw, idx, cam, prm, nthreads=cores)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or frames >= 64:
+            break
+    rays = w * h * wl["spp"] * frames
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
+                sample="%d whole %dx%d frames (%d spp) through the oracle's CPU LBVH, %d threads, %.1f s"
+                       % (frames, w, h, wl["spp"], cores, dt)), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to time")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    w, h, spp = wl["width"], wl["height"], wl["spp"]
+    flags = wl["flags"] | (R.BRUTE_FORCE if args.brute_force else 0)
+    tile = 64
+    # A stream of our own, made torch's current stream: the library launches on it, RCCL orders against it and
+    # torch.cuda.Event records on it (a NULL handle would make the library create a private stream).
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx = R.Context(local_rank, stream=stream.cuda_stream)
+    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))  # every rank holds the whole scene
+    ntri, nnodes, scene_bytes = scene.counts()
+    cam = R.camera_reference(w, h)
+    prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world)
+    npix, _ = R.tile_layout(prm)
+    # one buffer, three planes (colour, depth, primitive id), 4 bytes per pixel each
+    planes = torch.empty(3, npix, dtype=torch.int32, device="cuda")
+    ptr = [planes[i].data_ptr() for i in range(3)]
+    gathered = frame = None
+    if world > 1 and rank == 0:
+        gathered = torch.empty(world, 3, npix, dtype=torch.int32, device="cuda")
+        frame = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
+    prm0 = R.make_params(w, h, tile=tile, nranks=world)
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev0[i].record(stream)
+        scene.render_device(cam, prm, ptr[0], ptr[1], ptr[2])
+        if i is not None:
+            ev1[i].record(stream)
+        if world > 1:
+            dist.gather(planes, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                for k in range(3):  # plane k of rank r starts at gathered[r, k]
+                    ctx.deinterleave(prm0, gathered[0, k].data_ptr(), frame[k].data_ptr(), rank_stride=3 * npix)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        rays_per_step = w * h * spp
+        value = rays_per_step * args.steps / elapsed / 1e6
+        # HBM roofline of the render kernel: every pixel's colour, depth and primitive id written once,
+        # triangles (48 B) and LBVH nodes (64 B) read once per frame per GPU.
+        alg_bytes = 12 * (npix if world > 1 else w * h) + scene_bytes
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "Mrays/s (primary + AO) bunny @1080p, 1/2/4/8 MI355X; % HBM/VALU roofline",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "mesh": "bunny (2503 v / 4968 f, regenerated from the fixture)",
+                       "width": w, "height": h, "spp": spp, "ao_rays": 0, "flags": int(flags),
+                       "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile,
+                       "parallelism": "tiles%%%d + RCCL gather to rank 0" % world if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_render_brute" if args.brute_force else "k_render_bvh",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, oracle_out = cpu_baseline(wl)
+            # outputs are compared before the timing is accepted
+            got = planes.cpu().numpy()
+            ok = (np.array_equal(got[2].view(np.uint32).reshape(h, w), oracle_out[2])
+                  and np.array_equal(got[1].view(np.uint32).reshape(h, w), oracle_out[1].view(np.uint32))
+                  and np.array_equal(got[0].view(np.uint8).reshape(h, w, 4), oracle_out[0]))
+            if not ok:
+                raise SystemExit("GPU output differs from the CPU oracle: timing rejected")
+            base["outputs_match_gpu"] = True
+            result["cpu_baseline"] = base
+        print(json.dumps(result))
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,9 +132,11 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
 /* Number of pixels rank `rank` owns and, optionally, the tile ids in the order they are stored. */
 int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_ids, uint32_t tile_ids_cap,
                     uint32_t* ntiles);
-/* Rank 0 after the gather: scatter `nranks` tile-major buffers (concatenated in rank order) into one row-major
- * frame.  Device pointers on the context's GPU; elem_size is 4 for every attachment. */
-int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, void* frame, uint32_t elem_size);
+/* Rank 0 after the gather: scatter `nranks` tile-major buffers into one row-major frame.  Rank r's buffer starts
+ * `rank_stride` elements after rank r-1's (0 = back to back).  Device pointers on the context's GPU; elem_size is
+ * 4 for every attachment.  Only enqueues. */
+int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, uint64_t rank_stride, void* frame,
+                     uint32_t elem_size);
 
 const char* inv_last_error(void);
 const char* inv_version(void);

@@ -90,7 +90,7 @@ def lib():
     L.inv_vertex_shader.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int]
     L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_tile_layout.argtypes = [C.POINTER(Params), u64p, u32p, C.c_uint32, u32p]
-    L.inv_deinterleave.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_uint32]
+    L.inv_deinterleave.argtypes = [vp, C.POINTER(Params), vp, C.c_uint64, vp, C.c_uint32]
     _lib = L
     return L
 
@@ -184,8 +184,9 @@ class Context:
     def synchronize(self):
         _chk(lib().inv_ctx_synchronize(self._h))
 
-    def deinterleave(self, prm: Params, gathered_ptr: int, frame_ptr: int):
-        _chk(lib().inv_deinterleave(self._h, C.byref(prm), C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), 4))
+    def deinterleave(self, prm: Params, gathered_ptr: int, frame_ptr: int, rank_stride: int = 0):
+        _chk(lib().inv_deinterleave(self._h, C.byref(prm), C.c_void_p(gathered_ptr), rank_stride,
+                                    C.c_void_p(frame_ptr), 4))
 
     def close(self):
         if self._h:

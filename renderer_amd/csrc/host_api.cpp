@@ -406,7 +406,8 @@ int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_
     return INV_OK;
 }
 
-int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, void* frame, uint32_t elem_size) {
+int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, uint64_t rank_stride, void* frame,
+                     uint32_t elem_size) {
     if (!ctx || !params || !gathered || !frame) return fail(INV_ERR_ARG, "inv_deinterleave: null argument");
     if (elem_size != 4) return fail(INV_ERR_ARG, "inv_deinterleave: elem_size must be 4");
     FrameK f;
@@ -416,7 +417,9 @@ int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathere
     int rc = fill_layout(p, &f);
     if (rc != INV_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(launch_deinterleave(ctx->stream, f, (const uint32_t*)gathered, (uint32_t*)frame));
+    const uint64_t own = (uint64_t)f.slots * f.tile * f.tile;
+    if (rank_stride != 0 && rank_stride < own) return fail(INV_ERR_ARG, "inv_deinterleave: rank_stride is smaller than one rank's buffer");
+    HIP_TRY(launch_deinterleave(ctx->stream, f, (const uint32_t*)gathered, rank_stride ? rank_stride : own, (uint32_t*)frame));
     return INV_OK;
 }
 

@@ -50,7 +50,8 @@ hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const 
                            const float* translations, uint32_t ninst, float* A, float* B, float* C);
 hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out);
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out);
-hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint32_t* frame);
+hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
+                               uint32_t* frame);
 // LBVH build over triA/B/C (reorders them into Morton order); scratch is allocated and freed inside.
 hipError_t build_lbvh(hipStream_t s, DeviceScene& sc);
 

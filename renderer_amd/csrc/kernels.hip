@@ -133,20 +133,21 @@ hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene
 // Rank 0 after the gather: tile-major buffers of all ranks -> one row-major frame.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_deinterleave(FrameK f, const uint32_t* __restrict__ gathered,
-                                                      uint32_t* __restrict__ frame) {
+                                                      uint64_t rank_stride, uint32_t* __restrict__ frame) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)f.w * f.h) return;
     uint32_t px = (uint32_t)(i % f.w), py = (uint32_t)(i / f.w);
     uint32_t id = (py / f.tile) * f.tiles_x + px / f.tile;
     uint32_t r = id % f.nranks, slot = id / f.nranks;
-    uint64_t src = ((uint64_t)r * f.slots + slot) * (f.tile * f.tile) + (py % f.tile) * f.tile + px % f.tile;
+    uint64_t src = (uint64_t)r * rank_stride + (uint64_t)slot * (f.tile * f.tile) + (py % f.tile) * f.tile + px % f.tile;
     frame[i] = gathered[src];
 }
 
-hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint32_t* frame) {
+hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
+                               uint32_t* frame) {
     uint64_t n = (uint64_t)f.w * f.h;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f, gathered, frame);
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f, gathered, rank_stride, frame);
     return hipGetLastError();
 }
 

@@ -160,14 +160,17 @@ def test_device_outputs_on_torch_stream(bunny_scene, bunny_path):
     """Device-pointer outputs on the caller's stream (the path bench.py times)."""
     import torch
     torch.cuda.set_device(0)
-    ctx = R.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = R.Context(0, stream=stream.cuda_stream)
     scene = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
     w, h = 1920, 1080
     color = torch.empty(h, w, 4, dtype=torch.uint8, device="cuda")
     depth = torch.empty(h, w, dtype=torch.float32, device="cuda")
     primid = torch.empty(h, w, dtype=torch.int32, device="cuda")
     scene.render_device(R.camera_reference(w, h), R.make_params(w, h), color.data_ptr(), depth.data_ptr(), primid.data_ptr())
-    torch.cuda.synchronize()
+    stream.synchronize()  # only the caller's stream: the draw must have been enqueued on it
+    torch.cuda.set_stream(torch.cuda.default_stream())
     got = (color.cpu().numpy(), depth.cpu().numpy(), primid.cpu().numpy().view(np.uint32))
     common.assert_frames_equal(got, common.golden_frame("bunny_1080_rect"), "device outputs")
     scene.close()
