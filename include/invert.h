@@ -50,6 +50,7 @@ enum {
     INV_INVERT = 2u,      /* post-pass c' = 255 - c on R,G,B of every pixel after the sRGB encode */
     INV_RGBA = 4u,        /* colour bytes R,G,B,A; default is B,G,R,A = VK_FORMAT_B8G8R8A8_SRGB memory order (src/invert.cpp:519) */
     INV_BRUTE_FORCE = 8u, /* test every triangle for every ray instead of traversing the LBVH */
+    INV_LANE_TRAVERSAL = 16u, /* one lane per ray with a stack in LDS instead of the tile kernel's candidate lists */
 };
 
 /* What the reference fixes as literals or takes from the window: extent (src/invert.cpp:779-791),
@@ -60,7 +61,7 @@ typedef struct inv_params {
     uint32_t ao_rays; /* ambient-occlusion rays per hit pixel; 0 = off */
     uint32_t flags;   /* INV_* */
     uint32_t seed;    /* jitter / AO hash seed */
-    uint32_t tile;    /* tile edge in pixels used to shard a frame over ranks; 0 is read as 64 */
+    uint32_t tile;    /* tile edge in pixels (a multiple of 32) used to shard a frame over ranks; 0 is read as 64 */
     uint32_t rank;    /* this context renders the tiles with tile_id % nranks == rank */
     uint32_t nranks;  /* 0 is read as 1 */
     float ao_tmax;    /* AO ray length; 0 = scene bounding-box diagonal */

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinvert_hip.so")
 
-LAMBERT, INVERT, RGBA, BRUTE_FORCE = 1, 2, 4, 8
+LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL = 1, 2, 4, 8, 16
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(8)
 
 # every symbol include/invert.h declares

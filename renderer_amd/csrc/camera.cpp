@@ -159,6 +159,8 @@ int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f) {
     f->d1x = (float)inv[0][1], f->d1y = (float)inv[1][1], f->d1z = (float)inv[2][1];
     f->d2x = (float)inv[0][2], f->d2y = (float)inv[1][2], f->d2z = (float)inv[2][2];
     f->p00 = P.c[0][0], f->p11 = P.c[1][1], f->p22 = P.c[2][2], f->p32 = P.c[3][2];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) f->mv[r * 4 + c] = VM.c[c][r];
     float reach = std::fmax(std::fabs(f->ox), std::fmax(std::fabs(f->oy), std::fabs(f->oz)));
     reach = std::fmax(reach, max_abs_coord);
     f->pad = reach * 0x1p-16f;
@@ -176,6 +178,35 @@ int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f) {
         f->lx = f->ly = f->lz = 0.0f;
     }
     return INV_OK;
+}
+
+// Pixel rectangle outside which no ray can hit the scene: the scene bounds grown by four guard pads, projected in
+// double precision, plus a two-pixel margin.  A box corner at or behind the eye plane gives the whole frame.
+void hit_rect(const FrameK& f, const float bbox[6], uint32_t rect[4]) {
+    rect[0] = 0, rect[1] = 0, rect[2] = f.w, rect[3] = f.h;
+    const double g = 4.0 * (double)f.pad;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int corner = 0; corner < 8; corner++) {
+        const double p[3] = {(corner & 1) ? (double)bbox[3] + g : (double)bbox[0] - g,
+                             (corner & 2) ? (double)bbox[4] + g : (double)bbox[1] - g,
+                             (corner & 4) ? (double)bbox[5] + g : (double)bbox[2] - g};
+        double v[3];
+        for (int r = 0; r < 3; r++)
+            v[r] = (double)f.mv[r * 4 + 0] * p[0] + (double)f.mv[r * 4 + 1] * p[1] + (double)f.mv[r * 4 + 2] * p[2] +
+                   (double)f.mv[r * 4 + 3];
+        const double wc = -v[2];
+        if (!(wc > 1e-9)) return;
+        const double sx = ((double)f.p00 * v[0] / wc + 1.0) * 0.5 * (double)f.w;
+        const double sy = ((double)f.p11 * v[1] / wc + 1.0) * 0.5 * (double)f.h;
+        xmin = std::fmin(xmin, sx), xmax = std::fmax(xmax, sx);
+        ymin = std::fmin(ymin, sy), ymax = std::fmax(ymax, sy);
+    }
+    if (!(xmin <= xmax) || !(ymin <= ymax)) return;
+    auto clampu = [](double v, double hi) { return (uint32_t)std::fmin(std::fmax(v, 0.0), hi); };
+    rect[0] = clampu(std::floor(xmin) - 2.0, (double)f.w);
+    rect[1] = clampu(std::floor(ymin) - 2.0, (double)f.h);
+    rect[2] = clampu(std::ceil(xmax) + 2.0, (double)f.w);
+    rect[3] = clampu(std::ceil(ymax) + 2.0, (double)f.h);
 }
 
 } // namespace inv

@@ -17,6 +17,8 @@ struct FrameK {
     float pad;                // guard pad: 2^-16 * max(|origin|, |scene coordinates|)
     float lx, ly, lz;         // unit direction towards the light in object space (Lambert); 0 if undefined
     float wf, hf;
+    float mv[12];             // rows 0..2 of view*model (object -> view space), 4 floats each
+    uint32_t rx0, ry0, rx1, ry1; // pixel rectangle that can contain hits (projected scene bounds); rest is clear
     uint32_t w, h;
     uint32_t spp, flags, seed;
     // tile sharding

@@ -64,7 +64,7 @@ void dfree(T*& p) {
 
 void free_device_scene(DeviceScene& d) {
     dfree(d.xyzw), dfree(d.idx), dfree(d.triA), dfree(d.triB), dfree(d.triC);
-    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.nodes);
+    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.nodes), dfree(d.cut);
 }
 
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).
@@ -80,7 +80,7 @@ int fill_layout(const inv_params& p, FrameK* f) {
     f->nranks = p.nranks ? p.nranks : 1u;
     f->rank = p.rank;
     if (f->rank >= f->nranks) return fail(INV_ERR_ARG, "params: rank must be below nranks");
-    if (f->tile > 1024u || (f->tile & 15u)) return fail(INV_ERR_ARG, "params: tile must be a multiple of 16, at most 1024");
+    if (f->tile > 1024u || (f->tile & 31u)) return fail(INV_ERR_ARG, "params: tile must be a multiple of 32, at most 1024");
     f->tiles_x = (p.width + f->tile - 1) / f->tile;
     uint32_t tiles_y = (p.height + f->tile - 1) / f->tile;
     f->ntiles = f->tiles_x * tiles_y;
@@ -358,6 +358,11 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
     int rc = fill_layout(*params, &f);
     if (rc != INV_OK) return rc;
     if ((rc = frame_from_camera(*cam, scene->max_abs, &f)) != INV_OK) return rc;
+    {
+        uint32_t rect[4] = {0, 0, f.w, f.h};
+        if (scene->d.has_bvh) hit_rect(f, scene->d.bbox, rect);
+        f.rx0 = rect[0], f.ry0 = rect[1], f.rx1 = rect[2], f.ry1 = rect[3];
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     Outputs dev = {nullptr, nullptr, nullptr};
     if (out->on_device) {

@@ -23,8 +23,12 @@ int parse_obj_text(const char* text, uint64_t size, std::vector<float>& xyzw, st
 void reference_camera(uint32_t width, uint32_t height, inv_camera* cam);
 // view*model, its inverse (double Gauss-Jordan rounded to float) and the Lambert light direction.
 int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f);
+// Pixel rectangle [x0, x1) x [y0, y1) outside which no ray can hit anything inside `bbox`.
+void hit_rect(const FrameK& f, const float bbox[6], uint32_t rect[4]);
 
 // kernels.hip -- launchers (all asynchronous on `stream`)
+constexpr uint32_t kCutNodes = 512, kCutLeaves = 512;
+
 struct DeviceScene {
     uint32_t nv = 0, ntri = 0;
     float* xyzw = nullptr;    // nv float4 (mesh vertices as uploaded)
@@ -38,7 +42,8 @@ struct DeviceScene {
     uint32_t* child = nullptr;     // 2*(ntri-1)
     uint32_t* parent = nullptr;    // ntri-1
     uint32_t* leaf_parent = nullptr; // ntri
-    float* nodes = nullptr;        // 16 floats per internal node: two child boxes, two child refs, height
+    float* nodes = nullptr;        // 16 floats per internal node: two child boxes, two child refs, leaf range
+    uint32_t* cut = nullptr;       // start set of the tile kernel's descent (see k_build_cut)
     bool has_bvh = false;
     uint32_t height = 0;           // height of the root (a node over two leaves has height 1)
     float bbox[6] = {0, 0, 0, 0, 0, 0};

@@ -269,7 +269,7 @@ __device__ __forceinline__ int delta(const uint64_t* __restrict__ m, uint32_t n,
 
 __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, uint32_t n,
                                                 uint32_t* __restrict__ child, uint32_t* __restrict__ parent,
-                                                uint32_t* __restrict__ leaf_parent) {
+                                                uint32_t* __restrict__ leaf_parent, float* __restrict__ nodes) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n - 1) return;
     if (i == 0) parent[0] = 0xFFFFFFFFu;
@@ -306,12 +306,16 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
     }
     child[2 * i] = c0;
     child[2 * i + 1] = c1;
+    // sorted leaves covered by this node: [lo, hi]; child 0 covers [lo, gamma], child 1 [gamma + 1, hi]
+    nodes[16 * i + 14] = __uint_as_float((uint32_t)lo);
+    nodes[16 * i + 15] = __uint_as_float((uint32_t)hi);
 }
 
 // ------------------------------------------------------------------------------------------
 // 6. refit: one lane per leaf walks to the root; the second lane to arrive at a node owns it.
-//    Node i (16 floats): child0 lo xyz, hi xyz, child1 lo xyz, hi xyz, child0, child1,
-//    subtree height, unused.  union_box[i] (8 floats) carries the node's own box upwards.
+//    Node i (16 floats): child0 lo xyz, hi xyz, child1 lo xyz, hi xyz, child0, child1, first and
+//    last sorted leaf under the node (written by the hierarchy kernel).  union_box[i] (8 floats)
+//    carries the node's own box and height upwards.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                const float4* __restrict__ TC, const float* union_box, float lo[3],
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void k_refit(const float4* __restrict__ TA, co
         uint32_t ht = 1u + (ht0 > ht1 ? ht0 : ht1);
         nd[0] = l0[0], nd[1] = l0[1], nd[2] = l0[2], nd[3] = h0[0], nd[4] = h0[1], nd[5] = h0[2];
         nd[6] = l1[0], nd[7] = l1[1], nd[8] = l1[2], nd[9] = h1[0], nd[10] = h1[1], nd[11] = h1[2];
-        nd[12] = __uint_as_float(c0), nd[13] = __uint_as_float(c1), nd[14] = __uint_as_float(ht), nd[15] = 0.0f;
+        nd[12] = __uint_as_float(c0), nd[13] = __uint_as_float(c1);
         float* u = union_box + 8 * (size_t)node;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -366,6 +370,36 @@ __global__ __launch_bounds__(256) void k_refit(const float4* __restrict__ TA, co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         node = parent[node];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// 7. cut: the internal nodes of the first level that holds more than kCutNodes/2 of them (at most
+//    kCutNodes), plus the leaves met above that level.  Tile kernels start their breadth-first
+//    descent here instead of at the root.
+//    cut[0] = #nodes, cut[1] = #leaves, then kCutNodes node slots, then kCutLeaves leaf slots.
+// ------------------------------------------------------------------------------------------
+__global__ void k_build_cut(const uint32_t* __restrict__ child, uint32_t* __restrict__ cut) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t* cur = cut + 2;
+    uint32_t* leaves = cut + 2 + kCutNodes;
+    uint32_t nxt[kCutNodes];
+    uint32_t ncur = 1, nleaf = 0;
+    cur[0] = 0;
+    while (ncur > 0 && ncur <= kCutNodes / 2 && nleaf + 2 * ncur <= kCutLeaves) {
+        uint32_t nn = 0;
+        for (uint32_t q = 0; q < ncur; q++)
+            for (int side = 0; side < 2; side++) {
+                uint32_t c = child[2 * (size_t)cur[q] + side];
+                if (c & 0x80000000u)
+                    leaves[nleaf++] = c & 0x7FFFFFFFu;
+                else
+                    nxt[nn++] = c;
+            }
+        for (uint32_t q = 0; q < nn; q++) cur[q] = nxt[q];
+        ncur = nn;
+    }
+    cut[0] = ncur;
+    cut[1] = nleaf;
 }
 
 #define HIP_RET(expr)                     \
@@ -414,6 +448,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     HIP_RET(hipMalloc((void**)&sc.parent, (size_t)(n - 1) * 4));
     HIP_RET(hipMalloc((void**)&sc.leaf_parent, (size_t)n * 4));
     HIP_RET(hipMalloc((void**)&sc.nodes, (size_t)(n - 1) * 64));
+    HIP_RET(hipMalloc((void**)&sc.cut, (size_t)(2 + kCutNodes + kCutLeaves) * 4));
     HIP_RET(hipMalloc((void**)&A1, (size_t)n * 16));
     HIP_RET(hipMalloc((void**)&B1, (size_t)n * 16));
     HIP_RET(hipMalloc((void**)&C1, (size_t)n * 16));
@@ -438,13 +473,16 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
         std::swap(vin, vout);
     }
     hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, A0, B0, C0, sc.order, n, A1, B1, C1);
-    hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent);
+    hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
+                       sc.nodes);
     HIP_RET(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, s));
     hipLaunchKernelGGL(k_refit, grid_n, blk, 0, s, (const float4*)A1, (const float4*)B1, (const float4*)C1, n, sc.child,
                        sc.parent, sc.leaf_parent, arrive, union_box, sc.nodes);
     HIP_RET(hipGetLastError());
     HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
-    HIP_RET(hipMemcpyAsync(&sc.height, sc.nodes + 14, 4, hipMemcpyDeviceToHost, s)); // root height
+    hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(1), 0, s, sc.child, sc.cut);
+    HIP_RET(hipGetLastError());
+    HIP_RET(hipMemcpyAsync(&sc.height, union_box + 6, 4, hipMemcpyDeviceToHost, s)); // root height
     HIP_RET(hipStreamSynchronize(s)); // scratch is freed on return
     (void)hipFree(sc.triA), (void)hipFree(sc.triB), (void)hipFree(sc.triC);
     sc.triA = (float*)A1, sc.triB = (float*)B1, sc.triC = (float*)C1;

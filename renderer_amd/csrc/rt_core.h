@@ -137,15 +137,10 @@ __device__ __forceinline__ uint32_t srgb8(float x) {
     return (uint32_t)lo;
 }
 
-// fragmentShader + interpolated vertex colour (src/shader.slang:27, 31-36), optional Lambert term
-__device__ __forceinline__ void shade_sample(const FrameK& f, const Hit& h, const float4* __restrict__ TA,
-                                             const float4* __restrict__ TB, const float4* __restrict__ TC, float& r,
-                                             float& g, float& b) {
-    if (h.key == kMissKey) {
-        r = g = b = 0.0f; // clear colour (src/invert.cpp:742)
-        return;
-    }
-    float4 A = TA[h.slot], B = TB[h.slot], C = TC[h.slot];
+// fragmentShader + interpolated vertex colour (src/shader.slang:27, 31-36), optional Lambert term.
+// A, B, C are the winning triangle's records.
+__device__ __forceinline__ void shade_hit(const FrameK& f, const Hit& h, const float4& A, const float4& B,
+                                          const float4& C, float& r, float& g, float& b) {
     float u = h.un / h.det, v = h.vn / h.det;
     float w0 = (1.0f - u) - v;
     float c0 = A.z * 10.0f, c1 = B.w * 10.0f, c2 = C.w * 10.0f;
@@ -165,6 +160,16 @@ __device__ __forceinline__ void shade_sample(const FrameK& f, const Hit& h, cons
         }
         r = r * L, g = g * L, b = b * L;
     }
+}
+
+__device__ __forceinline__ void shade_sample(const FrameK& f, const Hit& h, const float4* __restrict__ TA,
+                                             const float4* __restrict__ TB, const float4* __restrict__ TC, float& r,
+                                             float& g, float& b) {
+    if (h.key == kMissKey) {
+        r = g = b = 0.0f; // clear colour (src/invert.cpp:742)
+        return;
+    }
+    shade_hit(f, h, TA[h.slot], TB[h.slot], TC[h.slot], r, g, b);
 }
 
 // colour attachment store: sRGB encode, optional invert post-pass, B,G,R,A byte order

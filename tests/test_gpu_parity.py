@@ -21,7 +21,8 @@ def bunny_scene(gpu_ctx, bunny_path):
 
 
 def _oracle_params(oracle, prm):
-    return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays, prm.flags & ~R.BRUTE_FORCE, prm.seed)
+    return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays,
+                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL), prm.seed)
 
 
 def test_vertex_stage_matches_oracle(oracle, bunny_scene, bunny_mesh):
@@ -32,21 +33,25 @@ def test_vertex_stage_matches_oracle(oracle, bunny_scene, bunny_mesh):
     assert np.array_equal(col.view(np.uint32), ocol.view(np.uint32))
 
 
-@pytest.mark.parametrize("flags", [0, R.BRUTE_FORCE])
+MODES = [0, R.BRUTE_FORCE, R.LANE_TRAVERSAL]  # tile kernel (default), brute force, per-lane stack traversal
+
+
+@pytest.mark.parametrize("flags", MODES)
 def test_config1_512_against_golden(bunny_scene, flags):
     got = bunny_scene.render(R.camera_reference(512, 512), R.make_params(512, 512, flags=flags))
     common.assert_frames_equal(got, common.golden_frame("bunny_512"), "config 1")
     assert int((got[2] != 0xFFFFFFFF).sum()) == 5651
 
 
-def test_config2_1080_against_golden(bunny_scene):
-    got = bunny_scene.render(R.camera_reference(1920, 1080), R.make_params(1920, 1080))
+@pytest.mark.parametrize("mode", [0, R.LANE_TRAVERSAL])
+def test_config2_1080_against_golden(bunny_scene, mode):
+    got = bunny_scene.render(R.camera_reference(1920, 1080), R.make_params(1920, 1080, flags=mode))
     common.assert_frames_equal(got, common.golden_frame("bunny_1080_rect"), "config 2 (parity mode)")
     assert int((got[2] != 0xFFFFFFFF).sum()) == 25139
 
 
 @pytest.mark.parametrize("flags", [R.LAMBERT, R.INVERT, R.LAMBERT | R.INVERT, R.LAMBERT | R.INVERT | R.RGBA])
-@pytest.mark.parametrize("brute", [0, R.BRUTE_FORCE])
+@pytest.mark.parametrize("brute", MODES)
 def test_shading_modes_against_oracle(oracle, bunny_scene, bunny_mesh, flags, brute):
     w, h = 640, 360
     prm = R.make_params(w, h, flags=flags | brute)
@@ -63,7 +68,7 @@ def test_config2_timed_mode_1080_against_oracle(oracle, bunny_scene, bunny_mesh)
     common.assert_frames_equal(got, want, "config 2 (Lambert + invert)")
 
 
-@pytest.mark.parametrize("brute", [0, R.BRUTE_FORCE])
+@pytest.mark.parametrize("brute", MODES)
 def test_jittered_samples_against_oracle(oracle, bunny_scene, bunny_mesh, brute):
     w, h = 320, 240
     prm = R.make_params(w, h, spp=4, seed=11, flags=R.LAMBERT | brute)
@@ -93,7 +98,7 @@ def test_moved_camera(oracle, bunny_scene, bunny_mesh):
     cam.view[:] = view.reshape(-1).tolist()
     cam.model[:] = model.reshape(-1).tolist()
     ocam = oracle.Camera.from_buffer_copy(bytes(cam))
-    for flags in (0, R.LAMBERT):
+    for flags in (0, R.LAMBERT, R.LANE_TRAVERSAL):
         prm = R.make_params(w, h, flags=flags)
         got = bunny_scene.render(cam, prm)
         want = oracle.render_bvh(*bunny_mesh, ocam, _oracle_params(oracle, prm))
@@ -110,7 +115,7 @@ def test_random_soup_and_degenerate_triangles(oracle, gpu_ctx):
     scene = R.Scene(gpu_ctx, mesh)
     oxyzw, oidx = oracle.parse_obj(text)
     w, h = 300, 300
-    for flags in (0, R.BRUTE_FORCE, R.LAMBERT):
+    for flags in (0, R.BRUTE_FORCE, R.LAMBERT, R.LANE_TRAVERSAL):
         prm = R.make_params(w, h, flags=flags)
         got = scene.render(R.camera_reference(w, h), prm)
         want = oracle.render_bruteforce(oxyzw, oidx, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
@@ -222,4 +227,38 @@ def test_lbvh_structure_random(oracle, gpu_ctx, ntri, seed):
     got = scene.render(R.camera_reference(256, 256), prm)
     want = oracle.render_bvh(xyzw, idx, oracle.camera_reference(256, 256), _oracle_params(oracle, prm))
     common.assert_frames_equal(got, want, "%d triangles" % ntri)
+    scene.close()
+
+
+@pytest.mark.parametrize("ntri,size", [(700, 0.02), (6000, 0.03)])
+def test_tile_kernel_list_overflow_paths(oracle, gpu_ctx, ntri, size):
+    """Dense overlapping soups at 64x64: the per-wave list (160) and the per-block list (1024) overflow, so the tile
+    kernel takes its two fallbacks (block list from memory; per-lane traversal)."""
+    xyz, faces = objfmt.random_soup(ntri, seed=9, lo=(-0.02, 0.08, -0.02), hi=(0.02, 0.12, 0.02), size=size)
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    idx = faces.reshape(-1).astype(np.uint32)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    for spp in (1, 3):
+        prm = R.make_params(64, 64, spp=spp, seed=3, flags=R.LAMBERT)
+        got = scene.render(R.camera_reference(64, 64), prm)
+        want = oracle.render_bvh(xyzw, idx, oracle.camera_reference(64, 64), _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "%d triangles spp=%d" % (ntri, spp))
+    scene.close()
+
+
+def test_camera_inside_the_scene(oracle, gpu_ctx):
+    """Eye inside the mesh's bounding box: the projected rectangle degenerates to the whole frame, boxes straddle
+    the eye plane."""
+    xyz, faces = objfmt.random_soup(500, seed=12, lo=(-0.3, -0.3, 0.7), hi=(0.3, 0.3, 1.3), size=0.08)
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    idx = faces.reshape(-1).astype(np.uint32)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    for mode in (0, R.LANE_TRAVERSAL):
+        prm = R.make_params(200, 150, flags=mode)
+        got = scene.render(R.camera_reference(200, 150), prm)
+        want = oracle.render_bruteforce(xyzw, idx, oracle.camera_reference(200, 150), _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "camera inside")
+    assert (got[2] != 0xFFFFFFFF).sum() > 1000
     scene.close()
