@@ -45,6 +45,26 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(workload, world):
+    """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary, or None.
+
+    The counters need separate profiler passes (FETCH_SIZE and WRITE_SIZE do not fit one), so they cannot be read
+    inside this process; tools/summarize_profiles.py writes profiles/*_pmc.json from those passes."""
+    import glob
+    if world != 1:
+        return None
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        k = doc.get("kernels", {}).get("k_render_tile")
+        if doc.get("workload") == workload and k:
+            best = k["hbm_bytes_per_launch"]
+    return best
+
+
 def cpu_baseline(wl, budget_s=8.0):
     """Time the CPU oracle on the same frame (bounded: whole frames until the budget is used)."""
     from oracle import oracle as O
@@ -117,15 +137,19 @@ def main():
         frame = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
     prm0 = R.make_params(w, h, tile=tile, nranks=world)
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # HIP events around every 4th launch of the timed region give the render kernel's duration
+    every = 4
+    nev = (args.steps + every - 1) // every
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
 
     def step(i=None):
-        if i is not None:
-            ev0[i].record(stream)
+        timed = i is not None and i % every == 0
+        if timed:
+            ev0[i // every].record(stream)
         scene.render_device(cam, prm, ptr[0], ptr[1], ptr[2])
-        if i is not None:
-            ev1[i].record(stream)
+        if timed:
+            ev1[i // every].record(stream)
         if world > 1:
             dist.gather(planes, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
             if rank == 0:
@@ -146,7 +170,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nev
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -170,8 +194,8 @@ def main():
                        "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile,
                        "parallelism": "tiles%%%d + RCCL gather to rank 0" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_render_brute" if args.brute_force else "k_render_bvh",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
+                         "kernel": "k_render_brute" if args.brute_force else "k_render_tile",
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
             "cpu_baseline": None,
         }

@@ -259,8 +259,13 @@ class Scene:
 
     def render_device(self, cam: Camera, prm: Params, color_ptr: int = 0, depth_ptr: int = 0, primid_ptr: int = 0):
         """Enqueue the draw into device buffers (e.g. torch tensors' data_ptr()) on the context's stream."""
-        out = Outputs(color_ptr or None, depth_ptr or None, primid_ptr or None, 1)
-        _chk(lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(out)))
+        key = (color_ptr, depth_ptr, primid_ptr)
+        if getattr(self, "_dev_out_key", None) != key:  # reuse the struct between frames into the same buffers
+            self._dev_out = Outputs(color_ptr or None, depth_ptr or None, primid_ptr or None, 1)
+            self._dev_out_key = key
+        rc = lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(self._dev_out))
+        if rc:
+            _chk(rc)
 
     def close(self):
         if self._h:

@@ -64,7 +64,7 @@ void dfree(T*& p) {
 
 void free_device_scene(DeviceScene& d) {
     dfree(d.xyzw), dfree(d.idx), dfree(d.triA), dfree(d.triB), dfree(d.triC);
-    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.nodes), dfree(d.cut);
+    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.nodes), dfree(d.cut), dfree(d.cut_groups);
 }
 
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).

@@ -27,7 +27,9 @@ int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f);
 void hit_rect(const FrameK& f, const float bbox[6], uint32_t rect[4]);
 
 // kernels.hip -- launchers (all asynchronous on `stream`)
-constexpr uint32_t kCutNodes = 512, kCutLeaves = 512;
+// Start set of the tile kernel: at most kCutCap subtrees (or single leaves) that together cover the scene, each
+// with its box; subtrees of at most kRangeMax leaves are taken whole as a range of the sorted triangle array.
+constexpr uint32_t kCutCap = 2048, kRangeMax = 16, kCutGroup = 16;
 
 struct DeviceScene {
     uint32_t nv = 0, ntri = 0;
@@ -43,7 +45,9 @@ struct DeviceScene {
     uint32_t* parent = nullptr;    // ntri-1
     uint32_t* leaf_parent = nullptr; // ntri
     float* nodes = nullptr;        // 16 floats per internal node: two child boxes, two child refs, leaf range
-    uint32_t* cut = nullptr;       // start set of the tile kernel's descent (see k_build_cut)
+    float* cut = nullptr;          // kCutCap records of 8 floats: lo xyz, first leaf | node, hi xyz, leaf count
+    float* cut_groups = nullptr;   // boxes of kCutGroup consecutive cut records: 8 floats each
+    uint32_t ncut = 0;             // records in use
     bool has_bvh = false;
     uint32_t height = 0;           // height of the root (a node over two leaves has height 1)
     float bbox[6] = {0, 0, 0, 0, 0, 0};

@@ -373,33 +373,53 @@ __global__ __launch_bounds__(256) void k_refit(const float4* __restrict__ TA, co
 }
 
 // ------------------------------------------------------------------------------------------
-// 7. cut: the internal nodes of the first level that holds more than kCutNodes/2 of them (at most
-//    kCutNodes), plus the leaves met above that level.  Tile kernels start their breadth-first
-//    descent here instead of at the root.
-//    cut[0] = #nodes, cut[1] = #leaves, then kCutNodes node slots, then kCutLeaves leaf slots.
+// 7. cut: a flat start set for the tile kernel.  The tree is opened breadth-first from the root
+//    until every open subtree has at most kRangeMax leaves or kCutCap records are in use.  A record
+//    is 8 floats: (lo.xyz, ref) (hi.xyz, count).  count <= kRangeMax: ref is the first sorted leaf
+//    of a range taken whole; otherwise ref is an internal node that still has to be descended.
+//    One lane does this (a few thousand dependent loads, once per scene).
 // ------------------------------------------------------------------------------------------
-__global__ void k_build_cut(const uint32_t* __restrict__ child, uint32_t* __restrict__ cut) {
+__global__ void k_build_cut(const float* __restrict__ nodes, float* __restrict__ cut, float* __restrict__ groups,
+                            uint32_t* __restrict__ ncut_out,
+                            uint32_t* __restrict__ queue /* 2 * kCutCap entries: (parent << 1) | side */) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t* cur = cut + 2;
-    uint32_t* leaves = cut + 2 + kCutNodes;
-    uint32_t nxt[kCutNodes];
-    uint32_t ncur = 1, nleaf = 0;
-    cur[0] = 0;
-    while (ncur > 0 && ncur <= kCutNodes / 2 && nleaf + 2 * ncur <= kCutLeaves) {
-        uint32_t nn = 0;
-        for (uint32_t q = 0; q < ncur; q++)
-            for (int side = 0; side < 2; side++) {
-                uint32_t c = child[2 * (size_t)cur[q] + side];
-                if (c & 0x80000000u)
-                    leaves[nleaf++] = c & 0x7FFFFFFFu;
-                else
-                    nxt[nn++] = c;
-            }
-        for (uint32_t q = 0; q < nn; q++) cur[q] = nxt[q];
-        ncur = nn;
+    uint32_t head = 0, tail = 0, nout = 0;
+    queue[tail++] = 0u; // root, side 0
+    queue[tail++] = 1u; // root, side 1
+    while (head < tail) {
+        const uint32_t e = queue[head++ % (2 * kCutCap)];
+        const uint32_t parent = e >> 1, side = e & 1u;
+        const float* nd = nodes + 16 * (size_t)parent;
+        const uint32_t c = __float_as_uint(nd[12 + side]);
+        const uint32_t gamma = __float_as_uint(nd[12]) & 0x7FFFFFFFu;
+        const uint32_t lo = __float_as_uint(nd[14]), hi = __float_as_uint(nd[15]);
+        const uint32_t first = side ? gamma + 1u : lo;
+        const uint32_t count = side ? hi - gamma : gamma - lo + 1u;
+        const bool small = (c & 0x80000000u) || count <= kRangeMax;
+        // opening a subtree replaces one pending record by two
+        if (!small && nout + (tail - head) + 2u <= kCutCap) {
+            queue[tail++ % (2 * kCutCap)] = 2u * c;
+            queue[tail++ % (2 * kCutCap)] = 2u * c + 1u;
+            continue;
+        }
+        float* r = cut + 8 * (size_t)nout++;
+        r[0] = nd[6 * side + 0], r[1] = nd[6 * side + 1], r[2] = nd[6 * side + 2];
+        r[3] = __uint_as_float(small ? first : c);
+        r[4] = nd[6 * side + 3], r[5] = nd[6 * side + 4], r[6] = nd[6 * side + 5];
+        r[7] = __uint_as_float(count);
     }
-    cut[0] = ncur;
-    cut[1] = nleaf;
+    *ncut_out = nout;
+    // boxes of kCutGroup consecutive records (breadth-first order keeps neighbours together): 8 floats per group
+    for (uint32_t g = 0; g * kCutGroup < nout; g++) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = g * kCutGroup; i < nout && i < (g + 1) * kCutGroup; i++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = fminf(lo[a], cut[8 * (size_t)i + a]);
+                hi[a] = fmaxf(hi[a], cut[8 * (size_t)i + 4 + a]);
+            }
+        float* r = groups + 8 * (size_t)g;
+        r[0] = lo[0], r[1] = lo[1], r[2] = lo[2], r[3] = 0.0f, r[4] = hi[0], r[5] = hi[1], r[6] = hi[2], r[7] = 0.0f;
+    }
 }
 
 #define HIP_RET(expr)                     \
@@ -448,7 +468,11 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     HIP_RET(hipMalloc((void**)&sc.parent, (size_t)(n - 1) * 4));
     HIP_RET(hipMalloc((void**)&sc.leaf_parent, (size_t)n * 4));
     HIP_RET(hipMalloc((void**)&sc.nodes, (size_t)(n - 1) * 64));
-    HIP_RET(hipMalloc((void**)&sc.cut, (size_t)(2 + kCutNodes + kCutLeaves) * 4));
+    HIP_RET(hipMalloc((void**)&sc.cut, (size_t)kCutCap * 32));
+    HIP_RET(hipMalloc((void**)&sc.cut_groups, (size_t)(kCutCap / kCutGroup) * 32));
+    uint32_t *cut_queue, *d_ncut;
+    HIP_RET(tmp.alloc(&cut_queue, (size_t)kCutCap * 8));
+    HIP_RET(tmp.alloc(&d_ncut, 16));
     HIP_RET(hipMalloc((void**)&A1, (size_t)n * 16));
     HIP_RET(hipMalloc((void**)&B1, (size_t)n * 16));
     HIP_RET(hipMalloc((void**)&C1, (size_t)n * 16));
@@ -480,8 +504,10 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
                        sc.parent, sc.leaf_parent, arrive, union_box, sc.nodes);
     HIP_RET(hipGetLastError());
     HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(1), 0, s, sc.child, sc.cut);
+    hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(1), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups, d_ncut,
+                       cut_queue);
     HIP_RET(hipGetLastError());
+    HIP_RET(hipMemcpyAsync(&sc.ncut, d_ncut, 4, hipMemcpyDeviceToHost, s));
     HIP_RET(hipMemcpyAsync(&sc.height, union_box + 6, 4, hipMemcpyDeviceToHost, s)); // root height
     HIP_RET(hipStreamSynchronize(s)); // scratch is freed on return
     (void)hipFree(sc.triA), (void)hipFree(sc.triB), (void)hipFree(sc.triC);

@@ -95,6 +95,8 @@ __device__ __forceinline__ void mt_test(const FrameK& f, const Ray& r, const flo
     float zc = f.p22 * (-t) + f.p32;
     float depth = zc / t;
     if (!(depth >= 0.0f && depth < 1.0f)) return; // near/far clip; LESS against the 1.0 clear (src/invert.cpp:793, 1384)
+    const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint64_t)__float_as_uint(A.w);
+    if (!(key < best.key)) return; // depth LESS, lower primitive wins ties (src/invert.cpp:1384 + draw order)
     // guard: the hit point lies inside the triangle's bounding box grown by the pad
     float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
     float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
@@ -102,12 +104,9 @@ __device__ __forceinline__ void mt_test(const FrameK& f, const Ray& r, const flo
     if (hx < fminf(A.x, fminf(bx, cx)) - f.pad || hx > fmaxf(A.x, fmaxf(bx, cx)) + f.pad) return;
     if (hy < fminf(A.y, fminf(by, cy)) - f.pad || hy > fmaxf(A.y, fmaxf(by, cy)) + f.pad) return;
     if (hz < fminf(A.z, fminf(bz, cz)) - f.pad || hz > fmaxf(A.z, fmaxf(bz, cz)) + f.pad) return;
-    uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint64_t)__float_as_uint(A.w);
-    if (key < best.key) { // depth LESS, lower primitive wins ties (src/invert.cpp:1384 + draw order)
-        best.key = key;
-        best.t = t, best.un = un, best.vn = vn, best.det = det;
-        best.slot = slot;
-    }
+    best.key = key;
+    best.t = t, best.un = un, best.vn = vn, best.det = det;
+    best.slot = slot;
 }
 
 __device__ __forceinline__ Hit miss_hit() {
@@ -123,18 +122,18 @@ static __device__ const float kSrgbT[256] = {
 #include "srgb_thresholds.inc"
 };
 
-__device__ __forceinline__ uint32_t srgb8(float x) {
-    if (!(x >= kSrgbT[1])) return 0u;
-    int lo = 1, hi = 255;
-#pragma unroll 1
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (x >= kSrgbT[mid])
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    return (uint32_t)lo;
+// The result is the unique k with T[k] <= x < T[k+1]; a hardware log2/exp2 estimate of the transfer
+// function lands on or next to it and the table decides, so the estimate's accuracy never shows.
+// `T` may point at the table in global memory or at a copy in LDS.
+__device__ __forceinline__ uint32_t srgb8(float x, const float* T) {
+    if (!(x >= 0x1.3e4568p-13f)) return 0u; // below T[1]; also NaN and negatives
+    if (x >= 0x1.fdb81cp-1f) return 255u;  // T[255]
+    const float s = x <= 0.0031308f ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
+    int k = (int)(255.0f * s + 0.5f);
+    k = k < 1 ? 1 : (k > 254 ? 254 : k);
+    while (x < T[k]) k--;      // stops at k = 1 at the latest: x >= T[1]
+    while (x >= T[k + 1]) k++; // stops at k = 254 at the latest: x < T[255]
+    return (uint32_t)k;
 }
 
 // fragmentShader + interpolated vertex colour (src/shader.slang:27, 31-36), optional Lambert term.
@@ -174,8 +173,8 @@ __device__ __forceinline__ void shade_sample(const FrameK& f, const Hit& h, cons
 
 // colour attachment store: sRGB encode, optional invert post-pass, B,G,R,A byte order
 // unless INV_RGBA (src/invert.cpp:519)
-__device__ __forceinline__ uint32_t pack_pixel(uint32_t flags, float r, float g, float b) {
-    uint32_t R = srgb8(r), G = srgb8(g), B = srgb8(b);
+__device__ __forceinline__ uint32_t pack_pixel(uint32_t flags, float r, float g, float b, const float* T = kSrgbT) {
+    uint32_t R = srgb8(r, T), G = (g == r) ? R : srgb8(g, T), B = srgb8(b, T);
     if (flags & INV_INVERT) R = 255u - R, G = 255u - G, B = 255u - B;
     uint32_t lo = (flags & INV_RGBA) ? R : B;
     uint32_t hi = (flags & INV_RGBA) ? B : R;

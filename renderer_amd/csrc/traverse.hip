@@ -23,6 +23,8 @@
 // slack on every comparison): every triangle that can pass the Moller-Trumbore test, whose hit point
 // must lie in the triangle's padded box, reaches that test.  The winner is the minimum
 // (depth, primitive) key, so neither the visiting order nor the superset of candidates changes a pixel.
+#include <cstdlib>
+
 #include "internal.h"
 #include "rt_core.h"
 
@@ -30,11 +32,13 @@ namespace inv {
 
 namespace {
 
+// timing-only switches in the high flag bits (images are wrong when set; used by tools/phase_timing.py)
+constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDebugSkipAll = 1u << 22, kDebugCounts = 1u << 23;
+
 constexpr int kStack = 40;        // per-lane stack entries; deeper trees use the brute-force kernel
 constexpr int kFrontierCap = 768;  // nodes per breadth-first level kept in LDS
 constexpr int kRangeCap = 512;     // leaf ranges per tile
 constexpr int kTileCap = 256;      // candidate triangle records per tile
-constexpr uint32_t kRangeMax = 16; // subtrees of at most this many leaves are not descended
 
 struct BlockMap {
     uint32_t px, py;
@@ -249,6 +253,7 @@ __device__ __forceinline__ bool out_index(const FrameK& f, uint32_t px, uint32_t
     return id % f.nranks == f.rank;
 }
 
+template <int NW>
 struct TileLds {
     union {
         struct {
@@ -258,67 +263,131 @@ struct TileLds {
         } t;
         uint32_t stack[kStack * 64]; // fallback: per-lane traversal by the first wave
     } u;
+    float srgb[256];             // copy of the sRGB threshold table
     unsigned long long best[64]; // per pixel: smallest (depth, primitive) key of the current sample
-    float acc[64][3];            // per pixel colour sum over samples
+    float4 win[64];              // per pixel: (un, vn, det, record slot) of the lane that holds the winning key
+    uint32_t groups[kCutCap / kCutGroup]; // cut groups whose box meets the tile's frustum
+    uint32_t n_groups;
     uint32_t n_front[2];
     uint32_t n_ranges;
     uint32_t n_rec;
     uint32_t overflow;
 };
 
-// The trace part of the grid: one workgroup (4 waves) per 8x8 pixel tile of the rectangle that can contain hits.
-__device__ __forceinline__ void trace_tile(const FrameK& f, TileLds& S, uint32_t tx0, uint32_t ty0,
+// Append `flag` lanes' values to an LDS list: one counter update per wave, lanes ranked by ballot.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool flag, uint32_t lane) {
+    const uint64_t mask = __ballot(flag);
+    uint32_t base = 0;
+    if (mask) {
+        if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+    }
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// The trace part of the grid: one workgroup of NW waves per 8x8 pixel tile of the rectangle that can contain hits.
+template <int NW>
+__device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint32_t tx0, uint32_t ty0,
                                            const float4* __restrict__ TA, const float4* __restrict__ TB,
                                            const float4* __restrict__ TC, const float4* __restrict__ nodes,
-                                           const uint32_t* __restrict__ cut, const Outputs& out) {
+                                           const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
+                                           uint32_t ncut, const Outputs& out) {
+    constexpr uint32_t NT = NW * 64;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const float grow = 2.0f * f.pad;
     const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u));
+    if (f.flags & kDebugSkipAll) return;
+    const bool stamps = (f.flags & kDebugCounts) && !(f.flags & kDebugSkipAfter2); // diagnostic build of the image
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
+    if (stamps) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- phase 1: breadth-first descent from the cut, one node per lane ----
-    const uint32_t ncut = cut[0], ncut_leaf = cut[1];
-    if (tid == 0) S.n_front[0] = ncut, S.n_front[1] = 0, S.n_ranges = ncut_leaf, S.n_rec = 0, S.overflow = 0;
-    for (uint32_t i = tid; i < ncut; i += 256) S.u.t.frontier[0][i] = cut[2 + i];
-    for (uint32_t i = tid; i < ncut_leaf; i += 256) S.u.t.ranges[i] = make_uint2(cut[2 + kCutNodes + i], 1u);
-    if (tid < 64) {
-        S.best[tid] = kMissKey;
-        S.acc[tid][0] = 0.0f, S.acc[tid][1] = 0.0f, S.acc[tid][2] = 0.0f;
+    // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
+    //      is still a subtree after that is opened breadth-first ----
+    if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
+    if (tid < 256) S.srgb[tid] = kSrgbT[tid];
+    if (tid < 64) S.best[tid] = kMissKey;
+    __syncthreads();
+    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
+    for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
+        const uint32_t g = base + tid;
+        bool in = false;
+        if (g < ngroups) {
+            const float4 lo = cut_groups[2 * (size_t)g], hi = cut_groups[2 * (size_t)g + 1];
+            in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, grow);
+        }
+        const uint32_t at = wave_append(&S.n_groups, in, lane);
+        if (in) S.groups[at] = g;
+    }
+    __syncthreads();
+    const uint32_t nsel = S.n_groups * kCutGroup;
+    for (uint32_t base = 0; base < nsel; base += NT) { // block-uniform trip count
+        const uint32_t q = base + tid;
+        bool to_range = false, to_front = false;
+        uint32_t ref = 0, count = 0;
+        if (q < nsel) {
+            const uint32_t i = S.groups[q / kCutGroup] * kCutGroup + q % kCutGroup;
+            if (i < ncut) {
+                const float4 lo = cut[2 * (size_t)i], hi = cut[2 * (size_t)i + 1];
+                ref = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
+                const bool in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, grow);
+                to_range = in && count <= kRangeMax;
+                to_front = in && count > kRangeMax;
+            }
+        }
+        const uint32_t ar = wave_append(&S.n_ranges, to_range, lane);
+        if (to_range) {
+            if (ar < (uint32_t)kRangeCap)
+                S.u.t.ranges[ar] = make_uint2(ref, count);
+            else
+                S.overflow = 1;
+        }
+        const uint32_t af = wave_append(&S.n_front[0], to_front, lane);
+        if (to_front) {
+            if (af < (uint32_t)kFrontierCap)
+                S.u.t.frontier[0][af] = ref;
+            else
+                S.overflow = 1;
+        }
     }
     __syncthreads();
     int cur = 0;
-    for (;;) {
+    for (;;) { // only scenes whose cut is capped still have subtrees to open here
         const uint32_t n = S.n_front[cur];
         if (n == 0 || S.overflow) break;
-        for (uint32_t base = 0; base < n; base += 256) {
+        for (uint32_t base = 0; base < n; base += NT) {
             const uint32_t q = base + tid;
+            bool in0 = false, in1 = false;
+            uint32_t c0 = 0, c1 = 0, lo = 0, hi = 0;
             if (q < n) {
                 const uint32_t node = S.u.t.frontier[cur][q];
                 const float4 q0 = nodes[4 * (size_t)node + 0], q1 = nodes[4 * (size_t)node + 1];
                 const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
-                const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                const uint32_t lo = __float_as_uint(q3.z), hi = __float_as_uint(q3.w);
-                const uint32_t gamma = c0 & 0x7FFFFFFFu;
-                const bool in0 = box_in_frustum(fr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, grow);
-                const bool in1 = box_in_frustum(fr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, grow);
+                c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                lo = __float_as_uint(q3.z), hi = __float_as_uint(q3.w);
+                in0 = box_in_frustum(fr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, grow);
+                in1 = box_in_frustum(fr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, grow);
+            }
+            const uint32_t gamma = c0 & 0x7FFFFFFFu;
 #pragma unroll
-                for (int side = 0; side < 2; side++) {
-                    if (!(side ? in1 : in0)) continue;
-                    const uint32_t c = side ? c1 : c0;
-                    const uint32_t first = side ? gamma + 1u : lo;
-                    const uint32_t count = side ? hi - gamma : gamma - lo + 1u;
-                    if ((c & 0x80000000u) || count <= kRangeMax) {
-                        const uint32_t at = atomicAdd(&S.n_ranges, 1u);
-                        if (at < (uint32_t)kRangeCap)
-                            S.u.t.ranges[at] = make_uint2(first, count);
-                        else
-                            S.overflow = 1;
-                    } else {
-                        const uint32_t at = atomicAdd(&S.n_front[cur ^ 1], 1u);
-                        if (at < (uint32_t)kFrontierCap)
-                            S.u.t.frontier[cur ^ 1][at] = c;
-                        else
-                            S.overflow = 1;
-                    }
+            for (int side = 0; side < 2; side++) {
+                const bool in = side ? in1 : in0;
+                const uint32_t c = side ? c1 : c0;
+                const uint32_t first = side ? gamma + 1u : lo;
+                const uint32_t count = side ? hi - gamma : gamma - lo + 1u;
+                const bool small = (c & 0x80000000u) || count <= kRangeMax;
+                const uint32_t ar = wave_append(&S.n_ranges, in && small, lane);
+                if (in && small) {
+                    if (ar < (uint32_t)kRangeCap)
+                        S.u.t.ranges[ar] = make_uint2(first, count);
+                    else
+                        S.overflow = 1;
+                }
+                const uint32_t af = wave_append(&S.n_front[cur ^ 1], in && !small, lane);
+                if (in && !small) {
+                    if (af < (uint32_t)kFrontierCap)
+                        S.u.t.frontier[cur ^ 1][af] = c;
+                    else
+                        S.overflow = 1;
                 }
             }
         }
@@ -327,8 +396,20 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds& S, uint32_t
         cur ^= 1;
         __syncthreads();
     }
-    __syncthreads();
 
+    const uint32_t px = tx0 + (lane & 7u), py = ty0 + (lane >> 3);
+    uint64_t oi = 0;
+    const bool valid = px < f.w && py < f.h && out_index(f, px, py, oi);
+    if (f.flags & kDebugSkipAfter1) return;
+    if (S.n_ranges == 0 && !S.overflow && !(f.flags & kDebugCounts)) { // nothing in this tile: clear values
+        if (wave == 0 && valid) {
+            if (out.depth) out.depth[oi] = 1.0f;
+            if (out.primid) out.primid[oi] = 0xFFFFFFFFu;
+            if (out.color) ((uint32_t*)out.color)[oi] = background_pixel(f.flags);
+        }
+        return;
+    }
+    if (stamps) t1 = __builtin_amdgcn_s_memtime();
     // ---- phase 2: one candidate triangle per lane against the tile's frustum and facing ----
     const uint32_t nranges = S.n_ranges;
     if (!S.overflow) {
@@ -340,7 +421,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds& S, uint32_t
         dir_at(f, (float)tx0 - m, (float)(ty0 + 8u) + m, cdx[2], cdy[2], cdz[2]);
         dir_at(f, (float)(tx0 + 8u) + m, (float)(ty0 + 8u) + m, cdx[3], cdy[3], cdz[3]);
         const uint32_t nslots = nranges * kRangeMax;
-        for (uint32_t base = 0; base < nslots; base += 256) { // block-uniform trip count
+        for (uint32_t base = 0; base < nslots; base += NT) { // block-uniform trip count
             const uint32_t q = base + tid;
             bool keep = false;
             float4 A, B, C;
@@ -368,11 +449,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds& S, uint32_t
                     keep = keep && !(dmax < -1e-4f * scale);
                 }
             }
-            const uint64_t mask = __ballot(keep);
-            uint32_t wbase = 0;
-            if (lane == 0 && mask) wbase = atomicAdd(&S.n_rec, (uint32_t)__popcll(mask));
-            wbase = __shfl(wbase, 0, 64);
-            const uint32_t at = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t at = wave_append(&S.n_rec, keep, lane);
             if (keep) {
                 if (at < (uint32_t)kTileCap) {
                     S.u.t.rec[at][0] = A;
@@ -386,65 +463,88 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds& S, uint32_t
     }
     __syncthreads();
 
-    const uint32_t px = tx0 + (lane & 7u), py = ty0 + (lane >> 3);
-    uint64_t oi = 0;
-    const bool valid = px < f.w && py < f.h && out_index(f, px, py, oi);
-
     if (S.overflow) { // more candidates than the LDS lists hold: the first wave traverses per lane
         if (wave == 0 && valid) pixel_by_traversal(f, px, py, oi, TA, TB, TC, nodes, S.u.stack + lane, 64, out);
         return;
     }
 
-    // ---- phase 3: every wave tests a quarter of the records for all 64 pixels; LDS min picks the winner ----
+    if (f.flags & kDebugSkipAfter2) {
+        if ((f.flags & kDebugCounts) && valid && wave == 0) { // list sizes instead of an image
+            if (out.depth) out.depth[oi] = __uint_as_float(S.n_ranges);
+            if (out.primid) out.primid[oi] = S.n_rec;
+        }
+        return;
+    }
+    if (stamps) t2 = __builtin_amdgcn_s_memtime();
+    // ---- phase 3: every wave tests its share of the records for all 64 pixels; an LDS min per pixel picks the
+    //      winning key; the lane that holds it hands its barycentric terms to the first wave, which shades ----
     const uint32_t nrec = S.n_rec;
     const uint32_t pix = py * f.w + px;
-    Hit first = miss_hit();
-    bool own_first = wave == 0;
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f; // first wave only
+    uint64_t first_key = kMissKey;
     for (uint32_t s = 0; s < f.spp; s++) {
         float sx, sy;
         sample_offset(pix, s, f.seed, sx, sy);
         const Ray ray = make_ray(f, px, py, sx, sy);
         Hit best = miss_hit();
-        for (uint32_t j = wave; j < nrec; j += 4)
+        for (uint32_t j = wave; j < nrec; j += NW)
             mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], j, best);
         if (best.key != kMissKey) atomicMin(&S.best[lane], (unsigned long long)best.key);
         __syncthreads();
-        const uint64_t win = S.best[lane];
-        // exactly one wave holds the winning record of a hit pixel (a triangle is listed once); wave 0 speaks for misses
-        const bool mine = (win == kMissKey) ? wave == 0 : best.key == win;
-        if (mine) {
-            float r = 0.0f, g = 0.0f, b = 0.0f;
-            if (win != kMissKey)
-                shade_hit(f, best, S.u.t.rec[best.slot][0], S.u.t.rec[best.slot][1], S.u.t.rec[best.slot][2], r, g, b);
-            S.acc[lane][0] = S.acc[lane][0] + r;
-            S.acc[lane][1] = S.acc[lane][1] + g;
-            S.acc[lane][2] = S.acc[lane][2] + b;
-            if (s == 0) first = best, own_first = true;
-        } else if (s == 0) {
-            own_first = false;
-        }
+        // exactly one wave holds the winning record of a hit pixel (a triangle is listed once)
+        if (best.key != kMissKey && best.key == S.best[lane])
+            S.win[lane] = make_float4(best.un, best.vn, best.det, __uint_as_float(best.slot));
         __syncthreads();
-        if (wave == 0) S.best[lane] = kMissKey;
+        if (wave == 0) {
+            const uint64_t key = S.best[lane];
+            float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
+            if (key != kMissKey) {
+                const float4 wv = S.win[lane];
+                Hit h;
+                h.key = key, h.t = 0.0f, h.un = wv.x, h.vn = wv.y, h.det = wv.z, h.slot = __float_as_uint(wv.w);
+                shade_hit(f, h, S.u.t.rec[h.slot][0], S.u.t.rec[h.slot][1], S.u.t.rec[h.slot][2], r, g, b);
+            }
+            sr = sr + r, sg = sg + g, sb = sb + b;
+            if (s == 0) first_key = key;
+            S.best[lane] = kMissKey;
+        }
         if (s + 1 < f.spp) __syncthreads();
     }
-    if (!valid) return;
-    if (own_first) { // the lane that won sample 0 stores depth and primitive id
-        if (out.depth) out.depth[oi] = __uint_as_float((uint32_t)(first.key >> 32));
-        if (out.primid) out.primid[oi] = (uint32_t)first.key;
+    if (stamps) { // cycles per phase of wave 0 instead of an image: lanes 0..3 of the tile's first row
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        if (wave == 0 && valid && out.depth) {
+            const unsigned long long r3 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long v = lane == 0 ? t1 - t0 : lane == 1 ? t2 - t1 : lane == 2 ? t3 - t2 : lane == 3 ? (unsigned long long)S.n_rec
+                                       : lane == 4 ? r3 - r0 : lane == 5 ? (t0 & 0xFFFFFFFFull) : lane == 6 ? (r0 & 0xFFFFFFFFull) : 0ull;
+            out.depth[oi] = __uint_as_float((uint32_t)v);
+        }
+        return;
     }
-    if (wave == 0 && out.color) {
-        const float n = (float)f.spp;
-        ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, S.acc[lane][0] / n, S.acc[lane][1] / n, S.acc[lane][2] / n);
+    if (wave != 0 || !valid) return;
+    if (out.depth) out.depth[oi] = __uint_as_float((uint32_t)(first_key >> 32));
+    if (out.primid) out.primid[oi] = (uint32_t)first_key;
+    if (out.color) {
+        if (f.spp > 1) { // x / 1 is x: the resolve division is only needed for several samples
+            const float n = (float)f.spp;
+            sr = sr / n, sg = sg / n, sb = sb / n;
+        }
+        ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, sr, sg, sb, S.srgb);
     }
 }
 
-// Grid = [8x8 tiles of the hit rectangle] ++ [32x8 blocks of the whole frame].  The second part stores the clear
-// values of every pixel whose 8x8 tile is not in the first part: two full 128-byte lines per wave and plane.
-__global__ __launch_bounds__(256) void k_render_tile(FrameK f, uint32_t tiles_x, uint32_t ntiles,
-                                                     const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                     const float4* __restrict__ TC, const float4* __restrict__ nodes,
-                                                     const uint32_t* __restrict__ cut, Outputs out) {
-    __shared__ TileLds S;
+// Grid = [8x8 tiles of the hit rectangle] ++ [fill blocks].  The fill blocks store the clear values of every pixel
+// whose 8x8 tile is not in the first part, grid-stride: 16 bytes per lane when the row length and the buffer
+// addresses allow it (vec4), else one pixel per lane in 32x8 pixel blocks (two 128-byte lines per wave-instruction).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tiles_x, uint32_t ntiles,
+                                                         uint32_t fill_blocks, uint32_t pixel_blocks, int vec4,
+                                                         const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                         const float4* __restrict__ TC, const float4* __restrict__ nodes,
+                                                         const float4* __restrict__ cut,
+                                                         const float4* __restrict__ cut_groups, uint32_t ncut,
+                                                         Outputs out) {
+    __shared__ TileLds<NW> S;
+    constexpr uint32_t NT = NW * 64;
     if (blockIdx.x < ntiles) {
         const uint32_t tx0 = (f.rx0 & ~7u) + (blockIdx.x % tiles_x) * 8u;
         const uint32_t ty0 = (f.ry0 & ~7u) + (blockIdx.x / tiles_x) * 8u;
@@ -452,22 +552,63 @@ __global__ __launch_bounds__(256) void k_render_tile(FrameK f, uint32_t tiles_x,
             uint64_t dummy;
             if (!out_index(f, tx0, ty0, dummy)) return;
         }
-        trace_tile(f, S, tx0, ty0, TA, TB, TC, nodes, cut, out);
+        trace_tile<NW>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, out);
         return;
     }
-    const BlockOrigin o = block_origin(f, blockIdx.x - ntiles);
-    if (!o.live) return;
-    const uint32_t cx = o.x0 + (threadIdx.x & 31u), cy = o.y0 + (threadIdx.x >> 5);
-    if (cx >= f.w || cy >= f.h) return;
-    const uint32_t hx0 = f.rx0 & ~7u, hy0 = f.ry0 & ~7u, hx1 = hx0 + tiles_x * 8u, hy1 = hy0 + (ntiles / (tiles_x ? tiles_x : 1u)) * 8u;
-    if (cx >= hx0 && cx < hx1 && cy >= hy0 && cy < hy1) return; // traced by the first part of the grid
-    const uint64_t i = o.out0 + (uint64_t)(threadIdx.x >> 5) * o.pitch + (threadIdx.x & 31u);
-    if (out.depth) out.depth[i] = 1.0f;
-    if (out.primid) out.primid[i] = 0xFFFFFFFFu;
-    if (out.color) ((uint32_t*)out.color)[i] = background_pixel(f.flags);
+    const uint32_t hx0 = f.rx0 & ~7u, hy0 = f.ry0 & ~7u;
+    const uint32_t hx1 = hx0 + tiles_x * 8u, hy1 = hy0 + (tiles_x ? ntiles / tiles_x : 0u) * 8u; // traced rectangle
+    const uint32_t bg = background_pixel(f.flags);
+    if (vec4) {
+        // 16 bytes (four pixels of a row) per lane and attachment, grid-stride: 1 KiB per wave-instruction
+        const uint32_t row4 = (f.nranks <= 1 ? f.w : f.tile) >> 2; // chunks per stored row
+        const uint64_t nchunks = f.npix >> 2;
+        const uint4 c4 = make_uint4(bg, bg, bg, bg), p4 = make_uint4(~0u, ~0u, ~0u, ~0u);
+        const float4 d4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        for (uint64_t c = (uint64_t)(blockIdx.x - ntiles) * NT + threadIdx.x; c < nchunks; c += (uint64_t)fill_blocks * NT) {
+            uint32_t px, py;
+            if (f.nranks <= 1) {
+                px = (uint32_t)(c % row4) << 2, py = (uint32_t)(c / row4);
+            } else {
+                const uint32_t per_tile = (f.tile * f.tile) >> 2;
+                const uint32_t slot = (uint32_t)(c / per_tile), rem = (uint32_t)(c % per_tile);
+                const uint32_t id = slot * f.nranks + f.rank;
+                if (id >= f.ntiles) continue;
+                px = (id % f.tiles_x) * f.tile + ((rem % row4) << 2);
+                py = (id / f.tiles_x) * f.tile + rem / row4;
+                if (px >= f.w || py >= f.h) continue;
+            }
+            if (px >= hx0 && px < hx1 && py >= hy0 && py < hy1) continue; // traced by the first part of the grid
+            if (out.depth) ((float4*)out.depth)[c] = d4;
+            if (out.primid) ((uint4*)out.primid)[c] = p4;
+            if (out.color) ((uint4*)out.color)[c] = c4;
+        }
+        return;
+    }
+    if (threadIdx.x >= 256) return; // the per-pixel path works in 32x8 pixel blocks of 256 lanes
+    for (uint32_t b = blockIdx.x - ntiles; b < pixel_blocks; b += fill_blocks) {
+        const BlockOrigin o = block_origin(f, b);
+        if (!o.live) continue;
+        const uint32_t cx = o.x0 + (threadIdx.x & 31u), cy = o.y0 + (threadIdx.x >> 5);
+        if (cx >= f.w || cy >= f.h) continue;
+        if (cx >= hx0 && cx < hx1 && cy >= hy0 && cy < hy1) continue;
+        const uint64_t i = o.out0 + (uint64_t)(threadIdx.x >> 5) * o.pitch + (threadIdx.x & 31u);
+        if (out.depth) out.depth[i] = 1.0f;
+        if (out.primid) out.primid[i] = 0xFFFFFFFFu;
+        if (out.color) ((uint32_t*)out.color)[i] = bg;
+    }
 }
 
 } // namespace
+
+// waves per tile workgroup: 4 unless INV_TILE_WAVES says 8 or 16 (tuning knob; 4 measured fastest on the bunny)
+static int tile_waves() {
+    static const int nw = [] {
+        const char* e = std::getenv("INV_TILE_WAVES");
+        const int v = e ? std::atoi(e) : 4;
+        return (v == 8 || v == 16) ? v : 4;
+    }();
+    return nw;
+}
 
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out) {
     if (f.npix == 0) return hipSuccess;
@@ -484,20 +625,35 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
                            (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, out);
         return hipGetLastError();
     }
-    uint32_t fill_blocks;
+    uint32_t pixel_blocks;
     if (f.nranks <= 1)
-        fill_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
+        pixel_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
     else
-        fill_blocks = f.slots * (f.tile >> 5) * (f.tile >> 3);
+        pixel_blocks = f.slots * (f.tile >> 5) * (f.tile >> 3);
+    const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+    const int vec4 = (f.w % 4u == 0) && aligned16(out.color) && aligned16(out.depth) && aligned16(out.primid);
     uint32_t tiles_x = 0, tiles_y = 0;
     if (f.rx1 > f.rx0 && f.ry1 > f.ry0) {
         tiles_x = ((f.rx1 + 7u) >> 3) - (f.rx0 >> 3);
         tiles_y = ((f.ry1 + 7u) >> 3) - (f.ry0 >> 3);
     }
     const uint32_t ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(k_render_tile, dim3(ntiles + fill_blocks), dim3(256), 0, s, f, tiles_x, ntiles,
-                       (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes,
-                       sc.cut, out);
+    const int nw = tile_waves();
+    const uint32_t nt = (uint32_t)nw * 64u;
+    const uint64_t fill_work = vec4 ? ((f.npix >> 2) + nt - 1u) / nt : pixel_blocks;
+    const uint32_t fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
+#define INV_LAUNCH_TILE(NW)                                                                                          \
+    hipLaunchKernelGGL(k_render_tile<NW>, dim3(ntiles + fill_blocks), dim3(NW * 64), 0, s, f, tiles_x, ntiles,       \
+                       fill_blocks, pixel_blocks, vec4, (const float4*)sc.triA, (const float4*)sc.triB,               \
+                       (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,                        \
+                       (const float4*)sc.cut_groups, sc.ncut, out)
+    if (nw == 8)
+        INV_LAUNCH_TILE(8);
+    else if (nw == 16)
+        INV_LAUNCH_TILE(16);
+    else
+        INV_LAUNCH_TILE(4);
+#undef INV_LAUNCH_TILE
     return hipGetLastError();
 }
 

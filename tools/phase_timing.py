@@ -1,0 +1,57 @@
+"""Where the tile kernel's time goes: A/B the kernel with phases cut off, interleaved in one process.
+
+    python tools/phase_timing.py [--width 1920 --height 1080 --spp 1 --rounds 30]
+
+The switches live in the high bits of inv_params.flags and make the images wrong; they exist only for this script.
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import objfmt  # noqa: E402
+import renderer_amd as R  # noqa: E402
+
+VARIANTS = [("full", 0), ("no phase 3", 1 << 20), ("no phase 2,3", 1 << 21), ("fill only", 1 << 22),
+            ("lane traversal", R.LANE_TRAVERSAL)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--rounds", type=int, default=30)
+    ap.add_argument("--flags", type=int, default=R.LAMBERT | R.INVERT)
+    a = ap.parse_args()
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = R.Context(0, stream=stream.cuda_stream)
+    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))
+    w, h = a.width, a.height
+    buf = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
+    cam = R.camera_reference(w, h)
+    times = {name: [] for name, _ in VARIANTS}
+    for rnd in range(a.rounds + 3):
+        for name, bits in VARIANTS:
+            prm = R.make_params(w, h, spp=a.spp, flags=a.flags | bits)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(10):
+                scene.render_device(cam, prm, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr())
+            e1.record(stream)
+            e1.synchronize()
+            if rnd >= 3:
+                times[name].append(e0.elapsed_time(e1) * 100.0)  # us per launch
+    for name, _ in VARIANTS:
+        t = times[name]
+        print("%-16s median %8.2f us   min %8.2f us" % (name, statistics.median(t), min(t)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""Per-tile statistics of the tile kernel: list sizes and in-kernel cycle stamps per phase.
+
+    python tools/tile_stats.py [--width 1920 --height 1080]
+
+Uses the diagnostic switches in the high bits of inv_params.flags (images are not produced).
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import objfmt  # noqa: E402
+import renderer_amd as R  # noqa: E402
+
+SKIP_AFTER2, COUNTS = 1 << 20, 1 << 23
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    a = ap.parse_args()
+    w, h = a.width, a.height
+    ctx = R.Context(0)
+    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))
+    cam = R.camera_reference(w, h)
+    _, d, p = scene.render(cam, R.make_params(w, h, flags=SKIP_AFTER2 | COUNTS))
+    nr, nrec = d.view(np.uint32)[::8, ::8], p[::8, ::8]
+    m = (nr < 100000) & (nrec < 100000)
+    print("tiles traced %d; ranges mean %.1f max %d; records mean %.1f max %d" %
+          (m.sum(), nr[m].mean(), nr[m].max(), nrec[m].mean(), nrec[m].max()))
+    print("records histogram [0,1,8,16,32,64,128,256):", np.histogram(nrec[m], bins=[0, 1, 8, 16, 32, 64, 128, 256])[0])
+    for _ in range(3):
+        _, d, _ = scene.render(cam, R.make_params(w, h, flags=R.LAMBERT | R.INVERT | COUNTS))
+    d = d.view(np.uint32)
+    ys, xs = np.nonzero(m)
+    t1, t2, t3, n = (d[::8, k::8][ys, xs].astype(np.int64) for k in range(4))
+    for name, t in (("phase 1", t1), ("phase 2", t2), ("phase 3", t3), ("total", t1 + t2 + t3)):
+        print("%-8s mean %6.0f  median %6.0f  max %6.0f cycles" % (name, t.mean(), np.median(t), t.max()))
+    real = d[::8, 4::8][ys, xs].astype(np.int64)  # 100 MHz ticks over the three phases
+    ok = real > 0
+    print("in-kernel clock: %.0f MHz (cycles / constant 100 MHz ticks, median over tiles)" %
+          np.median((t1 + t2 + t3)[ok] / real[ok] * 100.0))
+    start = d[::8, 6::8][ys, xs].astype(np.int64)
+    print("tile start spread: %.2f us; last tile end - first tile start: %.2f us" %
+          ((start.max() - start.min()) / 100.0, ((start + real).max() - start.min()) / 100.0))
+    i = int(np.argmax(t1 + t2 + t3))
+    print("slowest tile: %d records, phases %d / %d / %d cycles" % (n[i], t1[i], t2[i], t3[i]))
+    for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 256)):
+        k = (n >= lo) & (n < hi)
+        if k.any():
+            print("records [%3d,%3d): %4d tiles, phases %6.0f / %6.0f / %6.0f cycles" %
+                  (lo, hi, k.sum(), t1[k].mean(), t2[k].mean(), t3[k].mean()))
+
+
+if __name__ == "__main__":
+    main()
