@@ -32,6 +32,7 @@ import torch.distributed as dist  # noqa: E402
 
 import objfmt  # noqa: E402
 import renderer_amd as R  # noqa: E402
+from renderer_amd import dist as RD  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
@@ -96,6 +97,8 @@ def main():
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path on one GPU (ranks share cuda:0, gather through host memory)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,10 +111,14 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to time")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     w, h, spp = wl["width"], wl["height"], wl["spp"]
@@ -151,10 +158,15 @@ def main():
         if timed:
             ev1[i // every].record(stream)
         if world > 1:
-            dist.gather(planes, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if args.backend == "nccl":
+                RD.gather_to_rank0(planes, rank, world, gathered)
+            else:  # rehearsal: the collective runs on host copies
+                stream.synchronize()
+                host = RD.gather_to_rank0(planes.cpu(), rank, world)
+                if rank == 0:
+                    gathered.copy_(host)
             if rank == 0:
-                for k in range(3):  # plane k of rank r starts at gathered[r, k]
-                    ctx.deinterleave(prm0, gathered[0, k].data_ptr(), frame[k].data_ptr(), rank_stride=3 * npix)
+                RD.deinterleave_on_gpu(ctx, prm0, gathered, frame)
 
     for _ in range(args.warmup):
         step()
@@ -176,6 +188,15 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    if world > 1 and rank == 0:
+        # the composite must equal the same frame rendered by this rank alone
+        alone = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
+        scene.render_device(cam, R.make_params(w, h, spp=spp, flags=flags), alone[0].data_ptr(), alone[1].data_ptr(),
+                            alone[2].data_ptr())
+        stream.synchronize()
+        if not torch.equal(alone, frame):
+            raise SystemExit("composited frame differs from the single-GPU frame: timing rejected")
 
     if rank == 0:
         rays_per_step = w * h * spp

@@ -24,6 +24,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").split("(")[0]
+    name = name.split("<")[0]  # template arguments
+    for prefix in ("void ", "inv::"):
+        if name.startswith(prefix):
+            name = name[len(prefix):]
     return name.split("::")[-1]
 
 
