@@ -470,6 +470,74 @@ Shade make_shade(const orc_camera* cam, uint32_t flags) {
 }
 
 // ---------------------------------------------------------------------------
+// X5  ambient occlusion: cosine-weighted any-hit rays about the geometric normal
+// ---------------------------------------------------------------------------
+const float kAoDirs[256][2] = {
+#include "ao_dirs.inc"
+};
+
+// two-sided Moller-Trumbore with the same hit-point guard as the primary test
+inline bool mt_any(const Frame& f, V3 o, V3 w, float tmax, const Tri& tr) {
+    V3 p = cross(w, tr.e2);
+    float det = dot(tr.e1, p);
+    if (!(std::fabs(det) > 0.0f)) return false;
+    float inv = 1.0f / det;
+    V3 tv = sub(o, tr.v0);
+    float u = dot(tv, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    V3 q = cross(tv, tr.e1);
+    float v = dot(w, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    float t = dot(tr.e2, q) * inv;
+    if (!(t > 0.0f && t < tmax)) return false;
+    V3 lo, hi;
+    tri_bounds(tr, &lo, &hi);
+    float hx = o.x + t * w.x, hy = o.y + t * w.y, hz = o.z + t * w.z;
+    if (hx < lo.x - f.pad || hx > hi.x + f.pad) return false;
+    if (hy < lo.y - f.pad || hy > hi.y + f.pad) return false;
+    if (hz < lo.z - f.pad || hz > hi.z + f.pad) return false;
+    return true;
+}
+
+struct AoParams {
+    uint32_t rays;
+    float tmax;
+    uint32_t seed;
+};
+
+// Fraction of the hemisphere that is open, 1 - occluded / rays.  `occluded(o, w, tmax)` is the any-hit query.
+template <class AnyHit>
+inline float ao_factor(const Frame& f, const AoParams& ao, uint32_t pix, const Ray& r, const Best& b, const Tri& tr,
+                       AnyHit occluded) {
+    V3 n = cross(tr.e1, tr.e2);
+    float nn = dot(n, n);
+    if (!(nn > 0.0f)) return 1.0f;
+    float inv = 1.0f / std::sqrt(nn);
+    V3 nh = {n.x * inv, n.y * inv, n.z * inv};
+    float eps = 8.0f * f.pad;
+    V3 o = {(r.o.x + b.t * r.d.x) + nh.x * eps, (r.o.y + b.t * r.d.y) + nh.y * eps, (r.o.z + b.t * r.d.z) + nh.z * eps};
+    // orthonormal basis around nh (Duff et al., "Building an Orthonormal Basis, Revisited", JCGT 2017)
+    float sign = std::copysign(1.0f, nh.z);
+    float a = -1.0f / (sign + nh.z);
+    float bb = (nh.x * nh.y) * a;
+    V3 T = {1.0f + ((sign * nh.x) * nh.x) * a, sign * bb, -(sign * nh.x)};
+    V3 B = {bb, sign + (nh.y * nh.y) * a, -nh.y};
+    uint32_t hp = hash32(pix ^ hash32(ao.seed ^ 0xA0761D65u));
+    uint32_t occ = 0;
+    for (uint32_t k = 0; k < ao.rays; k++) {
+        uint32_t idx = ((k * 256u) / ao.rays + (hp & 255u)) & 255u;
+        uint32_t hk = hash32(hp + k * 0x9E3779B1u + 1u);
+        float u1 = (float)(hk >> 8) * 0x1p-24f;
+        float rr = std::sqrt(u1);
+        float x = rr * kAoDirs[idx][0], y = rr * kAoDirs[idx][1];
+        float z = std::sqrt(1.0f - u1);
+        V3 w = {(x * T.x + y * B.x) + z * nh.x, (x * T.y + y * B.y) + z * nh.y, (x * T.z + y * B.z) + z * nh.z};
+        if (occluded(o, w, ao.tmax)) occ++;
+    }
+    return 1.0f - (float)occ / (float)ao.rays;
+}
+
+// ---------------------------------------------------------------------------
 // LBVH (restatement of the GPU build, sequential)
 // ---------------------------------------------------------------------------
 struct Lbvh {
@@ -654,13 +722,40 @@ inline void trace_bvh(const Frame& f, const Ray& r, const std::vector<Tri>& tris
     }
 }
 
+inline bool any_bvh(const Frame& f, V3 o, V3 w, float tmax, const std::vector<Tri>& tris, const Lbvh& b,
+                    orc_counters* cnt) {
+    Ray r = {o, w};
+    V3 inv = {1.0f / w.x, 1.0f / w.y, 1.0f / w.z};
+    const float grow = 2.0f * f.pad;
+    uint32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        uint32_t node = stack[--sp];
+        const float* bx = &b.box[(size_t)node * 12];
+        for (int s = 0; s < 2; s++) {
+            float tn;
+            cnt->box_tests++;
+            if (!slab(r, inv, bx + 6 * s, bx + 6 * s + 3, grow, tmax * 1.0001f, &tn)) continue;
+            uint32_t c = b.child[2 * (size_t)node + s];
+            if (c & 0x80000000u) {
+                cnt->tri_tests++;
+                if (mt_any(f, o, w, tmax, tris[b.order[c & 0x7FFFFFFFu]])) return true;
+            } else {
+                stack[sp++] = c;
+            }
+        }
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------------------
 // frame driver
 // ---------------------------------------------------------------------------
-template <class TraceFn>
-void render_rows(const Frame& f, const Shade& sh, const orc_params* prm, const std::vector<Tri>& tris, uint32_t x0,
-                 uint32_t y0, uint32_t x1, uint32_t y1, int tid, int nthreads, uint8_t* color, float* depth,
-                 uint32_t* primid, TraceFn trace) {
+template <class TraceFn, class AnyFn>
+void render_rows(const Frame& f, const Shade& sh, const orc_params* prm, const AoParams& ao,
+                 const std::vector<Tri>& tris, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, int tid,
+                 int nthreads, uint8_t* color, float* depth, uint32_t* primid, TraceFn trace, AnyFn occluded) {
     uint32_t spp = prm->spp ? prm->spp : 1;
     float sppf = (float)spp;
     for (uint32_t py = y0 + (uint32_t)tid; py < y1; py += (uint32_t)nthreads) {
@@ -680,6 +775,10 @@ void render_rows(const Frame& f, const Shade& sh, const orc_params* prm, const s
                 }
                 float rgb[3];
                 shade_sample(sh, tris, best, rgb);
+                if (ao.rays && best.key != kMissKey) { // one sample per pixel in this mode (checked by the caller)
+                    float a = ao_factor(f, ao, pix, r, best, tris[(uint32_t)best.key], occluded);
+                    rgb[0] = rgb[0] * a, rgb[1] = rgb[1] * a, rgb[2] = rgb[2] * a;
+                }
                 sum[0] = sum[0] + rgb[0], sum[1] = sum[1] + rgb[1], sum[2] = sum[2] + rgb[2];
             }
             float rgb[3] = {sum[0] / sppf, sum[1] / sppf, sum[2] / sppf};
@@ -699,10 +798,26 @@ void run_threads(int nthreads, Body body) {
     for (auto& t : th) t.join();
 }
 
+AoParams make_ao(const orc_params* prm, const float* xyzw, uint32_t nv) {
+    AoParams ao = {prm->ao_rays, prm->ao_tmax, prm->seed};
+    if (ao.rays && !(ao.tmax > 0.0f)) { // default reach: diagonal of the vertices' bounding box
+        const float inf = std::numeric_limits<float>::infinity();
+        float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        for (uint32_t i = 0; i < nv; i++)
+            for (int c = 0; c < 3; c++) {
+                lo[c] = std::min(lo[c], xyzw[(size_t)i * 4 + c]);
+                hi[c] = std::max(hi[c], xyzw[(size_t)i * 4 + c]);
+            }
+        float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        ao.tmax = nv ? std::sqrt((ex * ex + ey * ey) + ez * ez) : 0.0f;
+    }
+    return ao;
+}
+
 int check_rect(const orc_params* prm, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
     if (prm->width == 0 || prm->height == 0) return 8;
     if (x0 > x1 || y0 > y1 || x1 > prm->width || y1 > prm->height) return 8;
-    if (prm->ao_rays != 0) return 9; // ambient occlusion is not part of this oracle yet
+    if (prm->ao_rays != 0 && prm->spp > 1) return 9; // ambient occlusion is defined for one sample per pixel
     return 0;
 }
 
@@ -776,10 +891,18 @@ int orc_render_bruteforce(const float* xyzw, uint32_t nv, const uint32_t* idx, u
     std::vector<Tri> tris;
     if ((rc = assemble(xyzw, nv, idx, nidx, tris))) return rc;
     Shade sh = make_shade(cam, prm->flags);
+    AoParams ao = make_ao(prm, xyzw, nv);
     run_threads(nthreads, [&](int tid, int nt) {
-        render_rows(f, sh, prm, tris, x0, y0, x1, y1, tid, nt, color, depth, primid, [&](const Ray& r, Best* best) {
-            for (uint32_t k = 0; k < (uint32_t)tris.size(); k++) mt_test(f, r, tris[k], k, best);
-        });
+        render_rows(
+            f, sh, prm, ao, tris, x0, y0, x1, y1, tid, nt, color, depth, primid,
+            [&](const Ray& r, Best* best) {
+                for (uint32_t k = 0; k < (uint32_t)tris.size(); k++) mt_test(f, r, tris[k], k, best);
+            },
+            [&](V3 o, V3 w, float tmax) {
+                for (uint32_t k = 0; k < (uint32_t)tris.size(); k++)
+                    if (mt_any(f, o, w, tmax, tris[k])) return true;
+                return false;
+            });
     });
     return 0;
 }
@@ -798,19 +921,30 @@ int orc_render_bvh(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t
     lbvh_build(tris, bvh);
     if (nthreads < 1) nthreads = 1;
     std::vector<orc_counters> cnt((size_t)nthreads, orc_counters{0, 0, 0, 0});
+    AoParams ao = make_ao(prm, xyzw, nv);
     run_threads(nthreads, [&](int tid, int nt) {
         orc_counters* c = &cnt[(size_t)tid];
-        render_rows(f, sh, prm, tris, x0, y0, x1, y1, tid, nt, color, depth, primid, [&](const Ray& r, Best* best) {
-            c->rays++;
-            if (tris.size() < 2) {
-                for (uint32_t k = 0; k < (uint32_t)tris.size(); k++) mt_test(f, r, tris[k], k, best);
-                c->tri_tests += tris.size();
-            } else {
-                // root box first (the node boxes stored in the root cover its children)
-                trace_bvh(f, r, tris, bvh, best, c);
-            }
-            if (best->key != kMissKey) c->hits++;
-        });
+        render_rows(
+            f, sh, prm, ao, tris, x0, y0, x1, y1, tid, nt, color, depth, primid,
+            [&](const Ray& r, Best* best) {
+                c->rays++;
+                if (tris.size() < 2) {
+                    for (uint32_t k = 0; k < (uint32_t)tris.size(); k++) mt_test(f, r, tris[k], k, best);
+                    c->tri_tests += tris.size();
+                } else {
+                    trace_bvh(f, r, tris, bvh, best, c);
+                }
+                if (best->key != kMissKey) c->hits++;
+            },
+            [&](V3 o, V3 w, float tmax) {
+                c->rays++;
+                if (tris.size() < 2) {
+                    for (uint32_t k = 0; k < (uint32_t)tris.size(); k++)
+                        if (mt_any(f, o, w, tmax, tris[k])) return true;
+                    return false;
+                }
+                return any_bvh(f, o, w, tmax, tris, bvh, c);
+            });
     });
     if (counters) {
         *counters = orc_counters{0, 0, 0, 0};

@@ -33,7 +33,7 @@ class Counters(C.Structure):
 
 def build() -> str:
     """Compile the oracle with gcc if the library is missing or stale."""
-    src = [os.path.join(_HERE, f) for f in ("oracle.cpp", "oracle.h", "srgb_thresholds.inc")]
+    src = [os.path.join(_HERE, f) for f in ("oracle.cpp", "oracle.h", "srgb_thresholds.inc", "ao_dirs.inc")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB

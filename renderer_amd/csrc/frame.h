@@ -26,6 +26,15 @@ struct FrameK {
     uint64_t npix;                                       // pixels this launch covers
 };
 
+// Ambient-occlusion pass: hit pixels are queued by the primary kernel and finished by k_ao.
+// A queue record is three float4: (origin.xyz, r) (normal.xyz, g) (b, pixel, out index low, out index high).
+struct AoK {
+    uint32_t rays;   // 0 = off
+    float tmax;
+    float* queue;    // 12 floats per record
+    uint32_t* count; // records queued (zeroed before the primary kernel)
+};
+
 struct Outputs {
     uint8_t* color;
     float* depth;

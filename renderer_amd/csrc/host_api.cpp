@@ -52,6 +52,9 @@ struct inv_scene {
     uint64_t stage_elems = 0;
     float* vs_stage = nullptr;
     uint64_t vs_stage_floats = 0;
+    float vertex_diag = 0.0f; // diagonal of the vertices' bounding box: default reach of occlusion rays
+    float* ao_queue = nullptr; // occlusion-pass queue (grow-only): 256-byte header with the counter, then records
+    uint64_t ao_cap = 0;
 };
 
 namespace {
@@ -237,6 +240,18 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
             }
         }
     s->max_abs = max_abs;
+    if (nv) { // bounding box of the vertices as stored (all instances)
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t j = 0; j < ninst; j++)
+            for (uint32_t i = 0; i < nv; i++)
+                for (int c = 0; c < 3; c++) {
+                    float v = mesh->xyzw[(size_t)i * 4 + c];
+                    if (translations_xyz) v = v + translations_xyz[(size_t)j * 3 + c];
+                    lo[c] = std::fmin(lo[c], v), hi[c] = std::fmax(hi[c], v);
+                }
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        s->vertex_diag = std::sqrt((ex * ex + ey * ey) + ez * ez);
+    }
     float* d_tr = nullptr;
     int rc = INV_OK;
     hipError_t e = hipSuccess;
@@ -298,6 +313,7 @@ int inv_scene_destroy(inv_scene* scene) {
     free_device_scene(scene->d);
     for (auto& p : scene->stage) dfree(p);
     dfree(scene->vs_stage);
+    dfree(scene->ao_queue);
     delete scene;
     return INV_OK;
 }
@@ -351,7 +367,9 @@ int inv_vertex_shader(inv_scene* scene, const inv_camera* cam, float* clip4, flo
 // ---- the draw ----------------------------------------------------------------------------------------
 int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out) {
     if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render: null argument");
-    if (params->ao_rays != 0) return fail(INV_ERR_UNSUPPORTED, "inv_render: ambient occlusion is not available in this build");
+    if (params->ao_rays != 0 && params->spp > 1)
+        return fail(INV_ERR_UNSUPPORTED, "inv_render: ambient occlusion is defined for one sample per pixel");
+    if (params->ao_rays > 4096) return fail(INV_ERR_ARG, "inv_render: at most 4096 ambient-occlusion rays per pixel");
     inv_ctx* ctx = scene->ctx;
     FrameK f;
     std::memset(&f, 0, sizeof f);
@@ -378,11 +396,26 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
         if (out->depth) dev.depth = (float*)scene->stage[1];
         if (out->primid) dev.primid = (uint32_t*)scene->stage[2];
     }
+    AoK ao = {0, 0.0f, nullptr, nullptr};
+    if (params->ao_rays) {
+        if (f.npix > scene->ao_cap) { // queue: one 48-byte record per pixel at most, plus the counter
+            dfree(scene->ao_queue);
+            scene->ao_cap = 0;
+            HIP_TRY(hipMalloc((void**)&scene->ao_queue, f.npix * 48 + 256));
+            scene->ao_cap = f.npix;
+        }
+        ao.rays = params->ao_rays;
+        ao.tmax = params->ao_tmax > 0.0f ? params->ao_tmax : scene->vertex_diag;
+        ao.count = (uint32_t*)scene->ao_queue;
+        ao.queue = scene->ao_queue + 64; // records start 256 bytes in
+        HIP_TRY(hipMemsetAsync(ao.count, 0, 256, ctx->stream));
+    }
     const bool brute = (params->flags & INV_BRUTE_FORCE) || !scene->d.has_bvh;
     if (brute)
-        HIP_TRY(launch_render_brute(ctx->stream, f, scene->d, dev));
+        HIP_TRY(launch_render_brute(ctx->stream, f, scene->d, ao, dev));
     else
-        HIP_TRY(launch_render_bvh(ctx->stream, f, scene->d, dev));
+        HIP_TRY(launch_render_bvh(ctx->stream, f, scene->d, ao, dev));
+    HIP_TRY(launch_ao(ctx->stream, f, scene->d, ao, dev));
     if (!out->on_device) {
         if (out->color) HIP_TRY(hipMemcpyAsync(out->color, dev.color, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (out->depth) HIP_TRY(hipMemcpyAsync(out->depth, dev.depth, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));

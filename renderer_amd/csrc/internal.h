@@ -57,8 +57,10 @@ hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, c
                                 float* color3);
 hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
                            const float* translations, uint32_t ninst, float* A, float* B, float* C);
-hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out);
-hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out);
+hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
+hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
+// Occlusion pass over the records the primary kernel queued (ao.rays > 0).
+hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
                                uint32_t* frame);
 // LBVH build over triA/B/C (reorders them into Morton order); scratch is allocated and freed inside.

@@ -89,16 +89,10 @@ hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const 
 // Brute force: one lane per pixel, every triangle tested (INV_BRUTE_FORCE).  The triangle index is
 // wave-uniform, so the records come in through scalar loads.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_pixel(const FrameK& f, const Outputs& out, uint64_t i, const Hit& first,
-                                            float r, float g, float b) {
-    if (out.depth) out.depth[i] = __uint_as_float((uint32_t)(first.key >> 32));
-    if (out.primid) out.primid[i] = (uint32_t)first.key;
-    if (out.color) ((uint32_t*)out.color)[i] = pack_pixel(f.flags, r, g, b);
-}
 
 __global__ __launch_bounds__(256) void k_render_brute(FrameK f, const float4* __restrict__ TA,
                                                       const float4* __restrict__ TB, const float4* __restrict__ TC,
-                                                      uint32_t ntri, Outputs out) {
+                                                      uint32_t ntri, AoK ao, Outputs out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= f.npix) return;
     uint32_t px, py;
@@ -106,6 +100,7 @@ __global__ __launch_bounds__(256) void k_render_brute(FrameK f, const float4* __
     uint32_t pix = py * f.w + px;
     float sr = 0.0f, sg = 0.0f, sb = 0.0f;
     Hit first = miss_hit();
+    Ray ray0 = make_ray(f, px, py, 0.5f, 0.5f);
     for (uint32_t s = 0; s < f.spp; s++) {
         float sx, sy;
         sample_offset(pix, s, f.seed, sx, sy);
@@ -117,15 +112,16 @@ __global__ __launch_bounds__(256) void k_render_brute(FrameK f, const float4* __
         shade_sample(f, best, TA, TB, TC, r, g, b);
         sr = sr + r, sg = sg + g, sb = sb + b;
     }
-    float n = (float)f.spp;
-    store_pixel(f, out, i, first, sr / n, sg / n, sb / n);
+    const uint32_t ws = first.key != kMissKey ? first.slot : 0u;
+    finish_pixel(f, ao, out, i, pix, ray0, first, TB[ws], TC[ws], sr, sg, sb);
 }
 
-hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out) {
+hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao,
+                               const Outputs& out) {
     if (f.npix == 0) return hipSuccess;
     uint64_t blocks = (f.npix + 255) / 256;
     hipLaunchKernelGGL(k_render_brute, dim3((unsigned)blocks), dim3(256), 0, s, f, (const float4*)sc.triA,
-                       (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, out);
+                       (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, ao, out);
     return hipGetLastError();
 }
 

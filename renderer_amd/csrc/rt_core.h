@@ -68,6 +68,22 @@ __device__ __forceinline__ Ray make_ray(const FrameK& f, uint32_t px, uint32_t p
     return r;
 }
 
+// The inside test of Moller-Trumbore on its own (same expressions and order as mt_test, no early exits):
+// true iff mt_test would go on to compute t for this triangle.
+__device__ __forceinline__ bool mt_inside(const Ray& r, const float4& A, const float4& B, const float4& C) {
+    float px = r.dy * C.z - r.dz * C.y;
+    float py = r.dz * C.x - r.dx * C.z;
+    float pz = r.dx * C.y - r.dy * C.x;
+    float det = (B.x * px + B.y * py) + B.z * pz;
+    float tx = r.ox - A.x, ty = r.oy - A.y, tz = r.oz - A.z;
+    float un = (tx * px + ty * py) + tz * pz;
+    float qx = ty * B.z - tz * B.y;
+    float qy = tz * B.x - tx * B.z;
+    float qz = tx * B.y - ty * B.x;
+    float vn = (r.dx * qx + r.dy * qy) + r.dz * qz;
+    return (det > 0.0f) & !(un < 0.0f) & !(un > det) & !(vn < 0.0f) & !(un + vn > det);
+}
+
 // Triangle record: three float4
 //   A = (v0.xyz, primitive id bits)   B = (e1.xyz, z of vertex 1)   C = (e2.xyz, z of vertex 2)
 // with e1 = v1 - v0, e2 = v2 - v0 rounded once at assembly.
@@ -171,6 +187,99 @@ __device__ __forceinline__ void shade_sample(const FrameK& f, const Hit& h, cons
     shade_hit(f, h, TA[h.slot], TB[h.slot], TC[h.slot], r, g, b);
 }
 
+// ---- ambient occlusion (cosine-weighted any-hit rays about the geometric normal) ----
+struct float2c {
+    float c, s;
+};
+static __device__ const float2c kAoDirs[256] = {
+#include "ao_dirs.inc"
+};
+
+// two-sided Moller-Trumbore with the same hit-point guard as the primary test
+__device__ __forceinline__ bool mt_any(const FrameK& f, float ox, float oy, float oz, float wx, float wy, float wz,
+                                       float tmax, const float4& A, const float4& B, const float4& C) {
+    float px = wy * C.z - wz * C.y;
+    float py = wz * C.x - wx * C.z;
+    float pz = wx * C.y - wy * C.x;
+    float det = (B.x * px + B.y * py) + B.z * pz;
+    if (!(fabsf(det) > 0.0f)) return false;
+    float inv = 1.0f / det;
+    float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
+    float u = ((tx * px + ty * py) + tz * pz) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    float qx = ty * B.z - tz * B.y;
+    float qy = tz * B.x - tx * B.z;
+    float qz = tx * B.y - ty * B.x;
+    float v = ((wx * qx + wy * qy) + wz * qz) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    float t = ((C.x * qx + C.y * qy) + C.z * qz) * inv;
+    if (!(t > 0.0f && t < tmax)) return false;
+    float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
+    float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
+    float hx = ox + t * wx, hy = oy + t * wy, hz = oz + t * wz;
+    if (hx < fminf(A.x, fminf(bx, cx)) - f.pad || hx > fmaxf(A.x, fmaxf(bx, cx)) + f.pad) return false;
+    if (hy < fminf(A.y, fminf(by, cy)) - f.pad || hy > fmaxf(A.y, fmaxf(by, cy)) + f.pad) return false;
+    if (hz < fminf(A.z, fminf(bz, cz)) - f.pad || hz > fmaxf(A.z, fmaxf(bz, cz)) + f.pad) return false;
+    return true;
+}
+
+// Unit normal of the winning triangle and the ray origin lifted off the surface by 8 guard pads.
+// false for a zero-area triangle (no occlusion is computed for it).
+__device__ __forceinline__ bool ao_origin(const FrameK& f, const Ray& r, float t, const float4& B, const float4& C,
+                                          float o[3], float n[3]) {
+    float nx = B.y * C.z - B.z * C.y;
+    float ny = B.z * C.x - B.x * C.z;
+    float nz = B.x * C.y - B.y * C.x;
+    float nn = (nx * nx + ny * ny) + nz * nz;
+    if (!(nn > 0.0f)) return false;
+    float inv = 1.0f / sqrtf(nn);
+    n[0] = nx * inv, n[1] = ny * inv, n[2] = nz * inv;
+    float eps = 8.0f * f.pad;
+    o[0] = (r.ox + t * r.dx) + n[0] * eps;
+    o[1] = (r.oy + t * r.dy) + n[1] * eps;
+    o[2] = (r.oz + t * r.dz) + n[2] * eps;
+    return true;
+}
+
+// Direction of occlusion ray k of a pixel: an orthonormal basis around n (Duff et al., JCGT 2017), a stratified
+// angle from the table and a hashed radius (Malley's method).
+__device__ __forceinline__ void ao_direction(const float n[3], uint32_t hp, uint32_t k, uint32_t rays, float w[3]) {
+    float sign = copysignf(1.0f, n[2]);
+    float a = -1.0f / (sign + n[2]);
+    float bb = (n[0] * n[1]) * a;
+    float Tx = 1.0f + ((sign * n[0]) * n[0]) * a, Ty = sign * bb, Tz = -(sign * n[0]);
+    float Bx = bb, By = sign + (n[1] * n[1]) * a, Bz = -n[1];
+    uint32_t idx = ((k * 256u) / rays + (hp & 255u)) & 255u;
+    uint32_t hk = hash32(hp + k * 0x9E3779B1u + 1u);
+    float u1 = (float)(hk >> 8) * 0x1p-24f;
+    float rr = sqrtf(u1);
+    float x = rr * kAoDirs[idx].c, y = rr * kAoDirs[idx].s;
+    float z = sqrtf(1.0f - u1);
+    w[0] = (x * Tx + y * Bx) + z * n[0];
+    w[1] = (x * Ty + y * By) + z * n[1];
+    w[2] = (x * Tz + y * Bz) + z * n[2];
+}
+
+// Queue one hit pixel for the occlusion pass: one counter update per wave, lanes ranked by ballot.
+// Call with the whole wave converged; `push` selects the lanes that have a record.
+__device__ __forceinline__ void ao_push(const AoK& ao, bool push, const float o[3], const float n[3], float r, float g,
+                                        float b, uint32_t pix, uint64_t out_index) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t mask = __ballot(push);
+    if (!mask) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(ao.count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (push) {
+        float4* q = (float4*)ao.queue + 3 * (size_t)(base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)));
+        q[0] = make_float4(o[0], o[1], o[2], r);
+        q[1] = make_float4(n[0], n[1], n[2], g);
+        q[2] = make_float4(b, __uint_as_float(pix), __uint_as_float((uint32_t)out_index),
+                           __uint_as_float((uint32_t)(out_index >> 32)));
+    }
+}
+
 // colour attachment store: sRGB encode, optional invert post-pass, B,G,R,A byte order
 // unless INV_RGBA (src/invert.cpp:519)
 __device__ __forceinline__ uint32_t pack_pixel(uint32_t flags, float r, float g, float b, const float* T = kSrgbT) {
@@ -183,6 +292,31 @@ __device__ __forceinline__ uint32_t pack_pixel(uint32_t flags, float r, float g,
 
 __device__ __forceinline__ uint32_t background_pixel(uint32_t flags) {
     return (flags & INV_INVERT) ? 0xFFFFFFFFu : 0xFF000000u;
+}
+
+// Resolve and store one pixel whose samples were traced by this lane.  sr/sg/sb are the summed linear
+// colours.  With ambient occlusion on (one sample per pixel) a hit pixel is queued for the occlusion pass,
+// which writes its colour, instead.  Every active lane of the wave must call this together.
+__device__ __forceinline__ void finish_pixel(const FrameK& f, const AoK& ao, const Outputs& out, uint64_t oi,
+                                             uint32_t pix, const Ray& ray0, const Hit& first, const float4& Bw,
+                                             const float4& Cw /* records B, C of the winner; unused for a miss */,
+                                             float sr, float sg, float sb, const float* T = kSrgbT) {
+    if (out.depth) out.depth[oi] = __uint_as_float((uint32_t)(first.key >> 32));
+    if (out.primid) out.primid[oi] = (uint32_t)first.key;
+    if (ao.rays) {
+        float o[3] = {0.0f, 0.0f, 0.0f}, n[3] = {0.0f, 0.0f, 0.0f};
+        bool push = false;
+        if (first.key != kMissKey) push = ao_origin(f, ray0, first.t, Bw, Cw, o, n);
+        ao_push(ao, push, o, n, sr, sg, sb, pix, oi);
+        if (push) return;
+    }
+    if (out.color) {
+        if (f.spp > 1) { // x / 1 is x: the resolve division is only needed for several samples
+            const float n = (float)f.spp;
+            sr = sr / n, sg = sg / n, sb = sb / n;
+        }
+        ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, sr, sg, sb, T);
+    }
 }
 
 // Work item -> pixel.  One rank: row-major.  Several ranks: this rank owns the

@@ -159,10 +159,12 @@ __device__ __forceinline__ void trace(const FrameK& f, const Ray& r, const float
 __device__ __forceinline__ void pixel_by_traversal(const FrameK& f, uint32_t px, uint32_t py, uint64_t out_index,
                                                    const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                    const float4* __restrict__ TC, const float4* __restrict__ nodes,
-                                                   uint32_t* stack, uint32_t stride, const Outputs& out) {
+                                                   uint32_t* stack, uint32_t stride, const AoK& ao,
+                                                   const Outputs& out) {
     const uint32_t pix = py * f.w + px;
     float sr = 0.0f, sg = 0.0f, sb = 0.0f;
     Hit first = miss_hit();
+    const Ray ray0 = make_ray(f, px, py, 0.5f, 0.5f);
     for (uint32_t s = 0; s < f.spp; s++) {
         float sx, sy;
         sample_offset(pix, s, f.seed, sx, sy);
@@ -174,19 +176,17 @@ __device__ __forceinline__ void pixel_by_traversal(const FrameK& f, uint32_t px,
         shade_sample(f, best, TA, TB, TC, r, g, b);
         sr = sr + r, sg = sg + g, sb = sb + b;
     }
-    const float n = (float)f.spp;
-    if (out.depth) out.depth[out_index] = __uint_as_float((uint32_t)(first.key >> 32));
-    if (out.primid) out.primid[out_index] = (uint32_t)first.key;
-    if (out.color) ((uint32_t*)out.color)[out_index] = pack_pixel(f.flags, sr / n, sg / n, sb / n);
+    const uint32_t ws = first.key != kMissKey ? first.slot : 0u;
+    finish_pixel(f, ao, out, out_index, pix, ray0, first, TB[ws], TC[ws], sr, sg, sb);
 }
 
 __global__ __launch_bounds__(256) void k_render_bvh(FrameK f, const float4* __restrict__ TA,
                                                     const float4* __restrict__ TB, const float4* __restrict__ TC,
-                                                    const float4* __restrict__ nodes, Outputs out) {
+                                                    const float4* __restrict__ nodes, AoK ao, Outputs out) {
     __shared__ uint32_t s_stack[kStack * 256];
     const BlockMap m = map_block16(f, blockIdx.x, threadIdx.x);
     if (!m.valid) return;
-    pixel_by_traversal(f, m.px, m.py, m.out, TA, TB, TC, nodes, s_stack + threadIdx.x, 256, out);
+    pixel_by_traversal(f, m.px, m.py, m.out, TA, TB, TC, nodes, s_stack + threadIdx.x, 256, ao, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,6 +266,7 @@ struct TileLds {
     float srgb[256];             // copy of the sRGB threshold table
     unsigned long long best[64]; // per pixel: smallest (depth, primitive) key of the current sample
     float4 win[64];              // per pixel: (un, vn, det, record slot) of the lane that holds the winning key
+    float win_t[64];             // and its ray parameter
     uint32_t groups[kCutCap / kCutGroup]; // cut groups whose box meets the tile's frustum
     uint32_t n_groups;
     uint32_t n_front[2];
@@ -291,7 +292,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                                            const float4* __restrict__ TA, const float4* __restrict__ TB,
                                            const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                            const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
-                                           uint32_t ncut, const Outputs& out) {
+                                           uint32_t ncut, const AoK& ao, const Outputs& out) {
     constexpr uint32_t NT = NW * 64;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const float grow = 2.0f * f.pad;
@@ -304,7 +305,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
     //      is still a subtree after that is opened breadth-first ----
     if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
-    if (tid < 256) S.srgb[tid] = kSrgbT[tid];
+    const float srgb_entry = kSrgbT[tid & 255u]; // stored to LDS later: the load stays in flight behind the first steps
     if (tid < 64) S.best[tid] = kMissKey;
     __syncthreads();
     const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
@@ -410,6 +411,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
         return;
     }
     if (stamps) t1 = __builtin_amdgcn_s_memtime();
+    if (tid < 256) S.srgb[tid] = srgb_entry;
     // ---- phase 2: one candidate triangle per lane against the tile's frustum and facing ----
     const uint32_t nranges = S.n_ranges;
     if (!S.overflow) {
@@ -464,7 +466,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     __syncthreads();
 
     if (S.overflow) { // more candidates than the LDS lists hold: the first wave traverses per lane
-        if (wave == 0 && valid) pixel_by_traversal(f, px, py, oi, TA, TB, TC, nodes, S.u.stack + lane, 64, out);
+        if (wave == 0 && valid) pixel_by_traversal(f, px, py, oi, TA, TB, TC, nodes, S.u.stack + lane, 64, ao, out);
         return;
     }
 
@@ -481,19 +483,29 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     const uint32_t nrec = S.n_rec;
     const uint32_t pix = py * f.w + px;
     float sr = 0.0f, sg = 0.0f, sb = 0.0f; // first wave only
-    uint64_t first_key = kMissKey;
+    Hit first = miss_hit();
+    const Ray ray0 = make_ray(f, px, py, 0.5f, 0.5f);
     for (uint32_t s = 0; s < f.spp; s++) {
         float sx, sy;
         sample_offset(pix, s, f.seed, sx, sy);
         const Ray ray = make_ray(f, px, py, sx, sy);
         Hit best = miss_hit();
-        for (uint32_t j = wave; j < nrec; j += NW)
+        // cheap pass: which of this wave's records contain the sample (one bit per record, no divergence) ...
+        uint64_t inside = 0;
+        for (uint32_t j = wave, i = 0; j < nrec; j += NW, i++)
+            inside |= (uint64_t)mt_inside(ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2]) << i;
+        // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
+        while (inside) {
+            const uint32_t i = (uint32_t)__ffsll((long long)inside) - 1u;
+            inside &= inside - 1ull;
+            const uint32_t j = wave + i * NW;
             mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], j, best);
+        }
         if (best.key != kMissKey) atomicMin(&S.best[lane], (unsigned long long)best.key);
         __syncthreads();
         // exactly one wave holds the winning record of a hit pixel (a triangle is listed once)
         if (best.key != kMissKey && best.key == S.best[lane])
-            S.win[lane] = make_float4(best.un, best.vn, best.det, __uint_as_float(best.slot));
+            S.win[lane] = make_float4(best.un, best.vn, best.det, __uint_as_float(best.slot)), S.win_t[lane] = best.t;
         __syncthreads();
         if (wave == 0) {
             const uint64_t key = S.best[lane];
@@ -501,11 +513,11 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
             if (key != kMissKey) {
                 const float4 wv = S.win[lane];
                 Hit h;
-                h.key = key, h.t = 0.0f, h.un = wv.x, h.vn = wv.y, h.det = wv.z, h.slot = __float_as_uint(wv.w);
+                h.key = key, h.t = S.win_t[lane], h.un = wv.x, h.vn = wv.y, h.det = wv.z, h.slot = __float_as_uint(wv.w);
                 shade_hit(f, h, S.u.t.rec[h.slot][0], S.u.t.rec[h.slot][1], S.u.t.rec[h.slot][2], r, g, b);
+                if (s == 0) first = h;
             }
             sr = sr + r, sg = sg + g, sb = sb + b;
-            if (s == 0) first_key = key;
             S.best[lane] = kMissKey;
         }
         if (s + 1 < f.spp) __syncthreads();
@@ -521,15 +533,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
         return;
     }
     if (wave != 0 || !valid) return;
-    if (out.depth) out.depth[oi] = __uint_as_float((uint32_t)(first_key >> 32));
-    if (out.primid) out.primid[oi] = (uint32_t)first_key;
-    if (out.color) {
-        if (f.spp > 1) { // x / 1 is x: the resolve division is only needed for several samples
-            const float n = (float)f.spp;
-            sr = sr / n, sg = sg / n, sb = sb / n;
-        }
-        ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, sr, sg, sb, S.srgb);
-    }
+    const uint32_t ws = first.key != kMissKey ? first.slot : 0u;
+    finish_pixel(f, ao, out, oi, pix, ray0, first, S.u.t.rec[ws][1], S.u.t.rec[ws][2], sr, sg, sb, S.srgb);
 }
 
 // Grid = [8x8 tiles of the hit rectangle] ++ [fill blocks].  The fill blocks store the clear values of every pixel
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
                                                          const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                                          const float4* __restrict__ cut,
                                                          const float4* __restrict__ cut_groups, uint32_t ncut,
-                                                         Outputs out) {
+                                                         AoK ao, Outputs out) {
     __shared__ TileLds<NW> S;
     constexpr uint32_t NT = NW * 64;
     if (blockIdx.x < ntiles) {
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
             uint64_t dummy;
             if (!out_index(f, tx0, ty0, dummy)) return;
         }
-        trace_tile<NW>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, out);
+        trace_tile<NW>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
         return;
     }
     const uint32_t hx0 = f.rx0 & ~7u, hy0 = f.ry0 & ~7u;
@@ -598,6 +603,91 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// occlusion pass: one wave per queued hit pixel, one lane per occlusion ray
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool any_hit_bvh(const FrameK& f, float ox, float oy, float oz, float wx, float wy,
+                                            float wz, float tmax, const float4* __restrict__ TA,
+                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                            const float4* __restrict__ nodes, uint32_t* stack, uint32_t stride) {
+    Ray r;
+    r.ox = ox, r.oy = oy, r.oz = oz, r.dx = wx, r.dy = wy, r.dz = wz;
+    const float ix = 1.0f / wx, iy = 1.0f / wy, iz = 1.0f / wz;
+    const float grow = 2.0f * f.pad, tlim = tmax * 1.0001f;
+    int sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+        const float4 q0 = nodes[4 * (size_t)node + 0], q1 = nodes[4 * (size_t)node + 1];
+        const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
+        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        float tn;
+        bool h0 = slab(r, ix, iy, iz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, grow, tlim, tn);
+        bool h1 = slab(r, ix, iy, iz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, grow, tlim, tn);
+        if (h0 && (c0 & 0x80000000u)) {
+            const uint32_t k = c0 & 0x7FFFFFFFu;
+            if (mt_any(f, ox, oy, oz, wx, wy, wz, tmax, TA[k], TB[k], TC[k])) return true;
+            h0 = false;
+        }
+        if (h1 && (c1 & 0x80000000u)) {
+            const uint32_t k = c1 & 0x7FFFFFFFu;
+            if (mt_any(f, ox, oy, oz, wx, wy, wz, tmax, TA[k], TB[k], TC[k])) return true;
+            h1 = false;
+        }
+        if (h0 && h1) {
+            stack[(size_t)sp * stride] = c1;
+            sp++;
+            node = c0;
+        } else if (h0) {
+            node = c0;
+        } else if (h1) {
+            node = c1;
+        } else {
+            if (sp == 0) return false;
+            sp--;
+            node = stack[(size_t)sp * stride];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __restrict__ TA,
+                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                            const float4* __restrict__ nodes, uint32_t ntri, int use_bvh,
+                                            Outputs out) {
+    __shared__ uint32_t s_stack[kStack * 256];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    const uint32_t count = *ao.count;
+    const float4* queue = (const float4*)ao.queue;
+    for (uint32_t rec = wave; rec < count; rec += nwaves) { // wave-uniform
+        const float4 q0 = queue[3 * (size_t)rec], q1 = queue[3 * (size_t)rec + 1], q2 = queue[3 * (size_t)rec + 2];
+        const float n[3] = {q1.x, q1.y, q1.z};
+        const uint32_t pix = __float_as_uint(q2.y);
+        const uint64_t oi = (uint64_t)__float_as_uint(q2.z) | ((uint64_t)__float_as_uint(q2.w) << 32);
+        const uint32_t hp = hash32(pix ^ hash32(f.seed ^ 0xA0761D65u));
+        uint32_t occ = 0;
+        for (uint32_t base = 0; base < ao.rays; base += 64) { // wave-uniform trip count
+            const uint32_t k = base + lane;
+            bool hit = false;
+            if (k < ao.rays) {
+                float w[3];
+                ao_direction(n, hp, k, ao.rays, w);
+                if (use_bvh) {
+                    hit = any_hit_bvh(f, q0.x, q0.y, q0.z, w[0], w[1], w[2], ao.tmax, TA, TB, TC, nodes,
+                                      s_stack + threadIdx.x, 256);
+                } else {
+                    for (uint32_t t = 0; t < ntri && !hit; t++)
+                        hit = mt_any(f, q0.x, q0.y, q0.z, w[0], w[1], w[2], ao.tmax, TA[t], TB[t], TC[t]);
+                }
+            }
+            occ += (uint32_t)__popcll(__ballot(hit));
+        }
+        if (lane == 0 && out.color) {
+            const float a = 1.0f - (float)occ / (float)ao.rays;
+            ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, q0.w * a, q1.w * a, q2.x * a);
+        }
+    }
+}
+
 } // namespace
 
 // waves per tile workgroup: 4 unless INV_TILE_WAVES says 8 or 16 (tuning knob; 4 measured fastest on the bunny)
@@ -610,9 +700,10 @@ static int tile_waves() {
     return nw;
 }
 
-hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const Outputs& out) {
+hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao,
+                             const Outputs& out) {
     if (f.npix == 0) return hipSuccess;
-    if (!sc.has_bvh || sc.height > (uint32_t)kStack) return launch_render_brute(s, f, sc, out);
+    if (!sc.has_bvh || sc.height > (uint32_t)kStack) return launch_render_brute(s, f, sc, ao, out);
     if (f.flags & INV_LANE_TRAVERSAL) {
         uint32_t blocks;
         if (f.nranks <= 1) {
@@ -622,7 +713,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
             blocks = f.slots * per * per;
         }
         hipLaunchKernelGGL(k_render_bvh, dim3(blocks), dim3(256), 0, s, f, (const float4*)sc.triA,
-                           (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, out);
+                           (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, ao, out);
         return hipGetLastError();
     }
     uint32_t pixel_blocks;
@@ -646,7 +737,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     hipLaunchKernelGGL(k_render_tile<NW>, dim3(ntiles + fill_blocks), dim3(NW * 64), 0, s, f, tiles_x, ntiles,       \
                        fill_blocks, pixel_blocks, vec4, (const float4*)sc.triA, (const float4*)sc.triB,               \
                        (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,                        \
-                       (const float4*)sc.cut_groups, sc.ncut, out)
+                       (const float4*)sc.cut_groups, sc.ncut, ao, out)
     if (nw == 8)
         INV_LAUNCH_TILE(8);
     else if (nw == 16)
@@ -657,4 +748,15 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     return hipGetLastError();
 }
 
+} // namespace inv
+
+namespace inv {
+hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out) {
+    if (!ao.rays || f.npix == 0) return hipSuccess;
+    const int use_bvh = sc.has_bvh && sc.height <= (uint32_t)kStack;
+    // a fixed grid walks the queue (its length is only known on the device): 4 waves per block, 4 blocks per CU
+    hipLaunchKernelGGL(k_ao, dim3(1024), dim3(256), 0, s, f, ao, (const float4*)sc.triA, (const float4*)sc.triB,
+                       (const float4*)sc.triC, (const float4*)sc.nodes, sc.ntri, use_bvh, out);
+    return hipGetLastError();
+}
 } // namespace inv

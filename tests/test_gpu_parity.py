@@ -22,7 +22,7 @@ def bunny_scene(gpu_ctx, bunny_path):
 
 def _oracle_params(oracle, prm):
     return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays,
-                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL), prm.seed)
+                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL), prm.seed, ao_tmax=prm.ao_tmax)
 
 
 def test_vertex_stage_matches_oracle(oracle, bunny_scene, bunny_mesh):
@@ -262,3 +262,50 @@ def test_camera_inside_the_scene(oracle, gpu_ctx):
         common.assert_frames_equal(got, want, "camera inside")
     assert (got[2] != 0xFFFFFFFF).sum() > 1000
     scene.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_ambient_occlusion_against_oracle(oracle, bunny_scene, bunny_mesh, mode):
+    """Occlusion rays (any-hit, incoherent) on top of each render mode; colour is the only attachment they change."""
+    w, h = 320, 240
+    prm = R.make_params(w, h, ao_rays=16, seed=5, flags=R.LAMBERT | mode)
+    got = bunny_scene.render(R.camera_reference(w, h), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "ao 16 rays mode %d" % mode)
+    plain = bunny_scene.render(R.camera_reference(w, h), R.make_params(w, h, flags=R.LAMBERT | mode))
+    hit = got[2] != 0xFFFFFFFF
+    assert (got[0][hit].astype(int) <= plain[0][hit].astype(int)).all() and (got[0][hit] < plain[0][hit]).any()
+
+
+@pytest.mark.parametrize("rays,flags,tmax", [(64, R.LAMBERT | R.INVERT, 0.0), (7, 0, 0.02), (100, R.RGBA, 0.0)])
+def test_ambient_occlusion_ray_counts(oracle, bunny_scene, bunny_mesh, rays, flags, tmax):
+    w, h = 400, 300
+    prm = R.make_params(w, h, ao_rays=rays, seed=1, flags=flags, ao_tmax=tmax)
+    got = bunny_scene.render(R.camera_reference(w, h), prm)
+    oprm = _oracle_params(oracle, prm)
+    oprm.ao_tmax = tmax
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), oprm)
+    common.assert_frames_equal(got, want, "ao %d rays" % rays)
+
+
+def test_ambient_occlusion_brute_force_oracle_small(oracle, bunny_scene, bunny_mesh):
+    """The oracle's own brute-force any-hit (no hierarchy anywhere) at a size it finishes in seconds."""
+    w, h = 160, 120
+    prm = R.make_params(w, h, ao_rays=16, seed=5, flags=R.LAMBERT)
+    got = bunny_scene.render(R.camera_reference(w, h), prm)
+    want = oracle.render_bruteforce(*bunny_mesh, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "ao vs brute-force oracle")
+
+
+def test_ambient_occlusion_config5_1080p(oracle, bunny_scene, bunny_mesh):
+    """1080p, 64 occlusion rays per hit pixel (about 1.6 M secondary rays)."""
+    prm = R.make_params(1920, 1080, ao_rays=64, flags=R.LAMBERT | R.INVERT)
+    got = bunny_scene.render(R.camera_reference(1920, 1080), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(1920, 1080), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "config 5")
+
+
+def test_ambient_occlusion_needs_one_sample_per_pixel(bunny_scene):
+    with pytest.raises(R.InvertError) as e:
+        bunny_scene.render(R.camera_reference(64, 64), R.make_params(64, 64, spp=2, ao_rays=8))
+    assert e.value.code == R.api.ERR_UNSUPPORTED

@@ -227,3 +227,23 @@ def test_sample_offsets(oracle):
     assert pts.min() >= 0.0 and pts.max() < 1.0
     assert abs(pts.mean() - 0.5) < 0.03 and len(np.unique(pts[:, 0])) > 1000
     assert oracle.sample_offset(5, 3, 1) != oracle.sample_offset(5, 3, 2)
+
+
+def test_occlusion_oracle_bvh_equals_brute_force(oracle, bunny_mesh):
+    xyzw, idx = bunny_mesh
+    cam = oracle.camera_reference(120, 90)
+    prm = oracle.make_params(120, 90, ao_rays=12, seed=3, flags=1)
+    a = oracle.render_bvh(xyzw, idx, cam, prm)
+    b = oracle.render_bruteforce(xyzw, idx, cam, prm)
+    common.assert_frames_equal(a, b, "ao")
+    plain = oracle.render_bvh(xyzw, idx, cam, oracle.make_params(120, 90, flags=1))
+    hit = a[2] != 0xFFFFFFFF
+    assert np.array_equal(a[1], plain[1]) and np.array_equal(a[2], plain[2])  # only colour changes
+    assert (a[0][hit].astype(int) <= plain[0][hit].astype(int)).all() and (a[0][hit] < plain[0][hit]).any()
+    # an open surface facing the camera with nothing around it is not occluded at all
+    tri = np.array([[-0.05, 0.05, 0.0], [0.05, 0.05, 0.0], [0.0, 0.15, 0.0]])
+    txyzw, tidx = oracle.parse_obj(__import__("objfmt").from_floats(tri, np.array([[0, 1, 2]], np.uint32)).text())
+    c = oracle.camera_reference(64, 64)
+    with_ao = oracle.render_bruteforce(txyzw, tidx, c, oracle.make_params(64, 64, ao_rays=32))
+    without = oracle.render_bruteforce(txyzw, tidx, c, oracle.make_params(64, 64))
+    assert np.array_equal(with_ao[0], without[0]) and (with_ao[2] != 0xFFFFFFFF).sum() > 20
