@@ -59,3 +59,27 @@ def slots_to_frame(slot_arrays, prm_w, prm_h, tile, nranks):
         ty, tx = divmod(tid, tiles_x)
         frame[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] = slot_arrays[r][slot]
     return frame[:prm_h, :prm_w]
+
+
+def grid_translations(n_side, spacing=0.2):
+    """n_side x n_side grid of instance translations in the xy plane, centred on the origin (float32)."""
+    c = (np.arange(n_side, dtype=np.float32) - np.float32((n_side - 1) / 2.0)) * np.float32(spacing)
+    gx, gy = np.meshgrid(c, c, indexing="xy")
+    return np.stack([gx.reshape(-1), gy.reshape(-1), np.zeros(n_side * n_side, np.float32)], axis=1).astype(np.float32)
+
+
+def flatten_instances(xyzw, idx, translations):
+    """What inv_scene_build_instanced assembles: translated copies (float32 adds), primitive id = inst*ntri + k."""
+    nv = xyzw.shape[0]
+    out_v = np.zeros((len(translations) * nv, 4), np.float32)
+    out_i = np.zeros(len(translations) * idx.size, np.uint32)
+    for j, t in enumerate(translations.astype(np.float32)):
+        out_v[j * nv:(j + 1) * nv, :3] = (xyzw[:, :3] + t[None, :]).astype(np.float32)
+        out_i[j * idx.size:(j + 1) * idx.size] = idx + np.uint32(j * nv)
+    return out_v, out_i
+
+
+def pulled_back_camera(cam, distance, height=0.11):
+    """The reference camera moved back along +z so that a grid of instances fits the view (same roll and lens)."""
+    cam.view[12], cam.view[13], cam.view[14] = 0.0, float(np.float32(height)), float(-np.float32(distance))
+    return cam

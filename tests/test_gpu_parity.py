@@ -309,3 +309,24 @@ def test_ambient_occlusion_needs_one_sample_per_pixel(bunny_scene):
     with pytest.raises(R.InvertError) as e:
         bunny_scene.render(R.camera_reference(64, 64), R.make_params(64, 64, spp=2, ao_rays=8))
     assert e.value.code == R.api.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_instanced_scene_small(oracle, gpu_ctx, bunny_path, bunny_mesh, mode):
+    """3x3 translated copies flattened into one LBVH; primitive id = instance * 4968 + face."""
+    tr = common.grid_translations(3)
+    scene = R.Scene(gpu_ctx, R.Mesh.load_obj(bunny_path), translations=tr)
+    assert scene.counts()[0] == 9 * 4968
+    fx, fi = common.flatten_instances(*bunny_mesh, tr)
+    w, h = 480, 360
+    cam = common.pulled_back_camera(R.camera_reference(w, h), 1.6)
+    ocam = oracle.Camera.from_buffer_copy(bytes(cam))
+    prm = R.make_params(w, h, flags=R.LAMBERT | mode)
+    got = scene.render(cam, prm)
+    want = oracle.render_bvh(fx, fi, ocam, _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "3x3 instances")
+    ids = got[2][got[2] != 0xFFFFFFFF]
+    assert len(np.unique(ids // 4968)) == 9
+    if mode == 0:
+        _check_lbvh(oracle, scene, fx, fi)
+    scene.close()
