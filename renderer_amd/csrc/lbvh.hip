@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __re
     counts[threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-// exclusive scan of `len` counters by one workgroup of 1024 threads (chunk per thread)
+// Exclusive scan of `len` counters.  Small arrays: one workgroup of 1024 threads, a chunk per thread.
 __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ counts, uint32_t len) {
     __shared__ uint32_t part[1024];
     uint32_t chunk = (len + 1023u) / 1024u;
@@ -150,6 +150,46 @@ __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ count
         counts[i] = run;
         run += c;
     }
+}
+
+// Large arrays: three launches.  (a) every workgroup scans its own kScanBlock counters in place and writes its
+// total, (b) one workgroup scans the totals (k_sort_scan), (c) every workgroup adds its offset.
+constexpr uint32_t kScanBlock = 4096; // 1024 threads x 4 counters
+
+__global__ __launch_bounds__(1024) void k_scan_local(uint32_t* __restrict__ counts, uint32_t len,
+                                                     uint32_t* __restrict__ totals) {
+    __shared__ uint32_t part[1024];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = base + k < len ? counts[base + k] : 0u;
+        sum += v[k];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t a = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += a;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (base + k < len) counts[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 1023) totals[blockIdx.x] = part[1023];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_add(uint32_t* __restrict__ counts, uint32_t len,
+                                                   const uint32_t* __restrict__ totals) {
+    const uint32_t off = totals[blockIdx.x]; // already scanned: exclusive prefix of the block totals
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (base + k < len) counts[base + k] += off;
 }
 
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* __restrict__ keys_in,
@@ -312,64 +352,66 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
 }
 
 // ------------------------------------------------------------------------------------------
-// 6. refit: one lane per leaf walks to the root; the second lane to arrive at a node owns it.
+// 6. refit, one launch per tree level.  A node is finished in the launch after the one in which
+//    its second child arrived, so every box a launch reads was written by an earlier launch and no
+//    data is handed between workgroups inside a launch; only the arrival counters are shared.
 //    Node i (16 floats): child0 lo xyz, hi xyz, child1 lo xyz, hi xyz, child0, child1, first and
 //    last sorted leaf under the node (written by the hierarchy kernel).  union_box[i] (8 floats)
 //    carries the node's own box and height upwards.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void arrive_at(uint32_t node, uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
+                                          uint32_t* __restrict__ next_count) {
+    if (node == 0xFFFFFFFFu) return;
+    if (atomicAdd(&arrive[node], 1u) == 1u) next[atomicAdd(next_count, 1u)] = node; // second child: ready next launch
+}
+
+__global__ __launch_bounds__(256) void k_refit_leaves(uint32_t n, const uint32_t* __restrict__ leaf_parent,
+                                                      uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
+                                                      uint32_t* __restrict__ next_count) {
+    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf < n) arrive_at(leaf_parent[leaf], arrive, next, next_count);
+}
+
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                               const float4* __restrict__ TC, const float* union_box, float lo[3],
-                                               float hi[3], uint32_t& height) {
+                                               const float4* __restrict__ TC, const float* __restrict__ union_box,
+                                               float lo[3], float hi[3], uint32_t& height) {
     if (c & 0x80000000u) {
         uint32_t k = c & 0x7FFFFFFFu;
         tri_box(TA[k], TB[k], TC[k], lo, hi);
         height = 0;
     } else {
-        // written by another workgroup earlier in this launch: agent-scope loads that bypass the L1
-        const float* u = union_box + 8 * (size_t)c;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            lo[a] = __hip_atomic_load(u + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hi[a] = __hip_atomic_load(u + 3 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        height = __float_as_uint(__hip_atomic_load(u + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float4 a = ((const float4*)union_box)[2 * (size_t)c], b = ((const float4*)union_box)[2 * (size_t)c + 1];
+        lo[0] = a.x, lo[1] = a.y, lo[2] = a.z, hi[0] = a.w, hi[1] = b.x, hi[2] = b.y;
+        height = __float_as_uint(b.z);
     }
 }
 
-__global__ __launch_bounds__(256) void k_refit(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                               const float4* __restrict__ TC, uint32_t n,
-                                               const uint32_t* __restrict__ child, const uint32_t* __restrict__ parent,
-                                               const uint32_t* __restrict__ leaf_parent, uint32_t* __restrict__ arrive,
-                                               float* union_box, float* __restrict__ nodes) {
-    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= n) return;
-    uint32_t node = leaf_parent[leaf];
-    // every lane ends at the root at the latest: the walk is bounded by the tree height
-    while (node != 0xFFFFFFFFu) {
-        uint32_t old = atomicAdd(&arrive[node], 1u); // device scope
-        if (old == 0) return;                        // the sibling subtree is not finished; its lane continues
-        __threadfence();                             // acquire: see what the first arrival published
-        uint32_t c0 = child[2 * (size_t)node], c1 = child[2 * (size_t)node + 1];
-        float l0[3], h0[3], l1[3], h1[3];
-        uint32_t ht0, ht1;
-        load_child_box(c0, TA, TB, TC, union_box, l0, h0, ht0);
-        load_child_box(c1, TA, TB, TC, union_box, l1, h1, ht1);
-        float* nd = nodes + 16 * (size_t)node;
-        uint32_t ht = 1u + (ht0 > ht1 ? ht0 : ht1);
-        nd[0] = l0[0], nd[1] = l0[1], nd[2] = l0[2], nd[3] = h0[0], nd[4] = h0[1], nd[5] = h0[2];
-        nd[6] = l1[0], nd[7] = l1[1], nd[8] = l1[2], nd[9] = h1[0], nd[10] = h1[1], nd[11] = h1[2];
-        nd[12] = __uint_as_float(c0), nd[13] = __uint_as_float(c1);
-        float* u = union_box + 8 * (size_t)node;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            __hip_atomic_store(u + a, fminf(l0[a], l1[a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(u + 3 + a, fmaxf(h0[a], h1[a]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __hip_atomic_store(u + 6, __uint_as_float(ht), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence(); // release before announcing arrival at the parent
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        node = parent[node];
-    }
+__global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                     const float4* __restrict__ TC, const uint32_t* __restrict__ child,
+                                                     const uint32_t* __restrict__ parent,
+                                                     const uint32_t* __restrict__ ready, uint32_t nready,
+                                                     uint32_t* __restrict__ arrive, float* __restrict__ union_box,
+                                                     float* __restrict__ nodes, uint32_t* __restrict__ next,
+                                                     uint32_t* __restrict__ next_count) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nready) return;
+    const uint32_t node = ready[q];
+    const uint32_t c0 = child[2 * (size_t)node], c1 = child[2 * (size_t)node + 1];
+    float l0[3], h0[3], l1[3], h1[3];
+    uint32_t ht0, ht1;
+    load_child_box(c0, TA, TB, TC, union_box, l0, h0, ht0);
+    load_child_box(c1, TA, TB, TC, union_box, l1, h1, ht1);
+    const uint32_t ht = 1u + (ht0 > ht1 ? ht0 : ht1);
+    float4* nd = (float4*)nodes + 4 * (size_t)node;
+    nd[0] = make_float4(l0[0], l0[1], l0[2], h0[0]);
+    nd[1] = make_float4(h0[1], h0[2], l1[0], l1[1]);
+    nd[2] = make_float4(l1[2], h1[0], h1[1], h1[2]);
+    nodes[16 * (size_t)node + 12] = __uint_as_float(c0);
+    nodes[16 * (size_t)node + 13] = __uint_as_float(c1);
+    float4* u = (float4*)union_box + 2 * (size_t)node;
+    u[0] = make_float4(fminf(l0[0], l1[0]), fminf(l0[1], l1[1]), fminf(l0[2], l1[2]), fmaxf(h0[0], h1[0]));
+    u[1] = make_float4(fmaxf(h0[1], h1[1]), fmaxf(h0[2], h1[2]), __uint_as_float(ht), 0.0f);
+    arrive_at(parent[node], arrive, next, next_count);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -460,6 +502,11 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     HIP_RET(tmp.alloc(&vals_alt, (size_t)n * 4));
     HIP_RET(tmp.alloc(&counts, (size_t)ntiles * 256 * 4));
     HIP_RET(tmp.alloc(&arrive, (size_t)(n - 1) * 4));
+    uint32_t *scan_totals, *ready[2], *ready_count;
+    HIP_RET(tmp.alloc(&scan_totals, ((size_t)ntiles * 256 / kScanBlock + 2) * 4));
+    HIP_RET(tmp.alloc(&ready[0], (size_t)(n - 1) * 4));
+    HIP_RET(tmp.alloc(&ready[1], (size_t)(n - 1) * 4));
+    HIP_RET(tmp.alloc(&ready_count, 256)); // one counter per level parity, 128 bytes apart
     HIP_RET(tmp.alloc(&union_box, (size_t)(n - 1) * 32));
     // persistent results
     HIP_RET(hipMalloc((void**)&sc.morton, (size_t)n * 8));
@@ -490,7 +537,15 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     for (int pass = 0; pass < 8; pass++) {
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, counts, ntiles * 256u);
+        const uint32_t ncount = ntiles * 256u;
+        if (ncount <= 16384u) {
+            hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, counts, ncount);
+        } else {
+            const uint32_t nb = (ncount + kScanBlock - 1) / kScanBlock;
+            hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(1024), 0, s, counts, ncount, scan_totals);
+            hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, scan_totals, nb);
+            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, counts, ncount, scan_totals);
+        }
         hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(kSortThreads), 0, s, kin, vin, n, shift, ntiles, counts,
                            kout, vout);
         std::swap(kin, kout);
@@ -500,14 +555,30 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        sc.nodes);
     HIP_RET(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, s));
-    hipLaunchKernelGGL(k_refit, grid_n, blk, 0, s, (const float4*)A1, (const float4*)B1, (const float4*)C1, n, sc.child,
-                       sc.parent, sc.leaf_parent, arrive, union_box, sc.nodes);
+    HIP_RET(hipMemsetAsync(ready_count, 0, 256, s));
+    hipLaunchKernelGGL(k_refit_leaves, grid_n, blk, 0, s, n, sc.leaf_parent, arrive, ready[0], ready_count);
     HIP_RET(hipGetLastError());
-    HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
+    uint32_t finished = 0;
+    for (int level = 0;; level++) { // one launch per level; the level's size comes back to the host
+        const int cur = level & 1;
+        uint32_t nready = 0;
+        HIP_RET(hipMemcpyAsync(&nready, ready_count + 32 * cur, 4, hipMemcpyDeviceToHost, s));
+        HIP_RET(hipStreamSynchronize(s));
+        if (nready == 0) break;
+        finished += nready;
+        HIP_RET(hipMemsetAsync(ready_count + 32 * (cur ^ 1), 0, 4, s));
+        hipLaunchKernelGGL(k_refit_level, dim3((nready + 255) / 256), blk, 0, s, (const float4*)A1, (const float4*)B1,
+                           (const float4*)C1, sc.child, sc.parent, ready[cur], nready, arrive, union_box, sc.nodes,
+                           ready[cur ^ 1], ready_count + 32 * (cur ^ 1));
+        if (level > 200) return hipErrorUnknown; // a tree over 63+32-bit keys is at most 96 levels deep
+    }
+    if (finished != n - 1) return hipErrorUnknown; // every internal node must have been refitted
+    HIP_RET(hipGetLastError());
     hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(1), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups, d_ncut,
                        cut_queue);
     HIP_RET(hipGetLastError());
     HIP_RET(hipMemcpyAsync(&sc.ncut, d_ncut, 4, hipMemcpyDeviceToHost, s));
+    HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
     HIP_RET(hipMemcpyAsync(&sc.height, union_box + 6, 4, hipMemcpyDeviceToHost, s)); // root height
     HIP_RET(hipStreamSynchronize(s)); // scratch is freed on return
     (void)hipFree(sc.triA), (void)hipFree(sc.triB), (void)hipFree(sc.triC);
