@@ -161,6 +161,8 @@ int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f) {
     f->p00 = P.c[0][0], f->p11 = P.c[1][1], f->p22 = P.c[2][2], f->p32 = P.c[3][2];
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 4; c++) f->mv[r * 4 + c] = VM.c[c][r];
+    f->inv_w2 = 2.0f / f->wf, f->inv_h2 = 2.0f / f->hf;
+    f->inv_p00 = 1.0f / f->p00, f->inv_p11 = 1.0f / f->p11;
     float reach = std::fmax(std::fabs(f->ox), std::fmax(std::fabs(f->oy), std::fabs(f->oz)));
     reach = std::fmax(reach, max_abs_coord);
     f->pad = reach * 0x1p-16f;

@@ -36,9 +36,9 @@ namespace {
 constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDebugSkipAll = 1u << 22, kDebugCounts = 1u << 23;
 
 constexpr int kStack = 40;        // per-lane stack entries; deeper trees use the brute-force kernel
-constexpr int kFrontierCap = 768;  // nodes per breadth-first level kept in LDS
-constexpr int kRangeCap = 512;     // leaf ranges per tile
-constexpr int kTileCap = 256;      // candidate triangle records per tile
+constexpr int kFrontierCap = 256;  // nodes per breadth-first level kept in LDS
+constexpr int kRangeCap = 256;     // leaf ranges per tile
+constexpr int kTileCap = 192;      // candidate triangle records per tile (at most 64 per wave: one mask bit each)
 
 struct BlockMap {
     uint32_t px, py;
@@ -204,9 +204,9 @@ struct Frustum {
 // [x0 - m, x1 + m] x [y0 - m, y1 + m] (pixels).  With clip = P * (V*M) * p and w_clip = -z_view:
 //   x_ndc >= xl  <=>  P00 * x_view + xl * z_view >= 0, and so on for the other three sides.
 __device__ __forceinline__ Frustum make_frustum(const FrameK& f, float x0, float y0, float x1, float y1) {
-    const float m = 0.0625f;
-    const float xl = (2.0f * (x0 - m)) / f.wf - 1.0f, xr = (2.0f * (x1 + m)) / f.wf - 1.0f;
-    const float yl = (2.0f * (y0 - m)) / f.hf - 1.0f, yr = (2.0f * (y1 + m)) / f.hf - 1.0f;
+    const float m = 0.0625f; // the 1/16 pixel of slack dwarfs the rounding of these reciprocal multiplies
+    const float xl = (x0 - m) * f.inv_w2 - 1.0f, xr = (x1 + m) * f.inv_w2 - 1.0f;
+    const float yl = (y0 - m) * f.inv_h2 - 1.0f, yr = (y1 + m) * f.inv_h2 - 1.0f;
     const float* r0 = f.mv;
     const float* r1 = f.mv + 4;
     const float* r2 = f.mv + 8;
@@ -233,10 +233,10 @@ __device__ __forceinline__ bool box_in_frustum(const Frustum& fr, float lx, floa
     return in;
 }
 
-// direction through framebuffer position (x, y), the same arithmetic as make_ray
+// direction through framebuffer position (x, y) for culling: make_ray's formula with reciprocal multiplies
 __device__ __forceinline__ void dir_at(const FrameK& f, float x, float y, float& dx, float& dy, float& dz) {
-    const float xn = (2.0f * x) / f.wf - 1.0f, yn = (2.0f * y) / f.hf - 1.0f;
-    const float dxv = xn / f.p00, dyv = yn / f.p11;
+    const float xn = x * f.inv_w2 - 1.0f, yn = y * f.inv_h2 - 1.0f;
+    const float dxv = xn * f.inv_p00, dyv = yn * f.inv_p11;
     dx = (f.d0x * dxv + f.d1x * dyv) - f.d2x;
     dy = (f.d0y * dxv + f.d1y * dyv) - f.d2y;
     dz = (f.d0z * dxv + f.d1z * dyv) - f.d2z;
