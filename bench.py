@@ -41,6 +41,8 @@ WORKLOADS = {
     "bunny_1080p_primary_lambert_invert": dict(width=1920, height=1080, spp=1, flags=R.LAMBERT | R.INVERT),
     # configs[2]: 4K, 16 jittered samples per pixel
     "bunny_4k_16spp": dict(width=3840, height=2160, spp=16, flags=R.LAMBERT | R.INVERT),
+    # configs[4]: 64 occlusion rays per hit pixel on top of configs[1]
+    "bunny_1080p_ao64": dict(width=1920, height=1080, spp=1, ao_rays=64, flags=R.LAMBERT | R.INVERT),
     # parity mode of configs[1]
     "bunny_1080p_parity": dict(width=1920, height=1080, spp=1, flags=0),
 }
@@ -73,7 +75,7 @@ def cpu_baseline(wl, budget_s=8.0):
     xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
     w, h = wl["width"], wl["height"]
     cam = O.camera_reference(w, h)
-    prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"])
+    prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"], ao_rays=wl.get("ao_rays", 0))
     cores = min(16, os.cpu_count() or 1)
     O.render_bvh(xyzw, idx, cam, prm, nthreads=cores)  # warm
     frames, t0 = 0, time.perf_counter()
@@ -83,7 +85,8 @@ def cpu_baseline(wl, budget_s=8.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or frames >= 64:
             break
-    rays = w * h * wl["spp"] * frames
+    hits = int((out[2] != 0xFFFFFFFF).sum())
+    rays = (w * h * wl["spp"] + wl.get("ao_rays", 0) * hits) * frames
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
                 sample="%d whole %dx%d frames (%d spp) through the oracle's CPU LBVH, %d threads, %.1f s"
                        % (frames, w, h, wl["spp"], cores, dt)), out
@@ -133,7 +136,8 @@ def main():
     scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))  # every rank holds the whole scene
     ntri, nnodes, scene_bytes = scene.counts()
     cam = R.camera_reference(w, h)
-    prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world)
+    ao_rays = wl.get("ao_rays", 0)
+    prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
     npix, _ = R.tile_layout(prm)
     # one buffer, three planes (colour, depth, primitive id), 4 bytes per pixel each
     planes = torch.empty(3, npix, dtype=torch.int32, device="cuda")
@@ -144,14 +148,18 @@ def main():
         frame = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
     prm0 = R.make_params(w, h, tile=tile, nranks=world)
 
-    # HIP events around every 4th launch of the timed region give the render kernel's duration
+    # Render-kernel duration: with one GPU two HIP events bracket the K launches of the timed region (the stream
+    # holds nothing else, so their distance / K is the average launch-to-launch time of the kernel; a pair of
+    # events around every launch would add about 3 us of marker latency to a 13 us kernel).  With several GPUs
+    # the stream also carries the gather, so there a pair of events brackets every 4th render launch.
     every = 4
     nev = (args.steps + every - 1) // every
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
+    ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def step(i=None):
-        timed = i is not None and i % every == 0
+        timed = world > 1 and i is not None and i % every == 0
         if timed:
             ev0[i // every].record(stream)
         scene.render_device(cam, prm, ptr[0], ptr[1], ptr[2])
@@ -175,14 +183,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev_begin.record(stream)
     for i in range(args.steps):
         step(i)
+    ev_end.record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nev
+    if world > 1:
+        kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nev
+    else:
+        kernel_ms = ev_begin.elapsed_time(ev_end) / args.steps
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -192,14 +205,16 @@ def main():
     if world > 1 and rank == 0:
         # the composite must equal the same frame rendered by this rank alone
         alone = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
-        scene.render_device(cam, R.make_params(w, h, spp=spp, flags=flags), alone[0].data_ptr(), alone[1].data_ptr(),
+        scene.render_device(cam, R.make_params(w, h, spp=spp, flags=flags, ao_rays=ao_rays), alone[0].data_ptr(), alone[1].data_ptr(),
                             alone[2].data_ptr())
         stream.synchronize()
         if not torch.equal(alone, frame):
             raise SystemExit("composited frame differs from the single-GPU frame: timing rejected")
 
     if rank == 0:
-        rays_per_step = w * h * spp
+        final = frame if world > 1 else planes
+        hit_pixels = int((final[2] != -1).sum()) if world == 1 or rank == 0 else 0
+        rays_per_step = w * h * spp + ao_rays * hit_pixels  # primary + occlusion rays of the whole frame
         value = rays_per_step * args.steps / elapsed / 1e6
         # HBM roofline of the render kernel: every pixel's colour, depth and primitive id written once,
         # triangles (48 B) and LBVH nodes (64 B) read once per frame per GPU.
@@ -211,12 +226,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "mesh": "bunny (2503 v / 4968 f, regenerated from the fixture)",
-                       "width": w, "height": h, "spp": spp, "ao_rays": 0, "flags": int(flags),
+                       "width": w, "height": h, "spp": spp, "ao_rays": ao_rays, "hit_pixels": hit_pixels,
+                       "rays_per_frame": rays_per_step, "flags": int(flags),
                        "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile,
                        "parallelism": "tiles%%%d + RCCL gather to rank 0" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
-                         "kernel": "k_render_brute" if args.brute_force else "k_render_tile",
+                         "kernel": ("k_render_brute" if args.brute_force else "k_render_tile") + ("+k_ao" if ao_rays else ""),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
             "cpu_baseline": None,
         }

@@ -410,6 +410,12 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
         ao.queue = scene->ao_queue + 64; // records start 256 bytes in
         HIP_TRY(hipMemsetAsync(ao.count, 0, 256, ctx->stream));
     }
+    // The tile kernel keeps an 8x8 tile's candidate triangles in LDS; where triangles are much smaller than a
+    // pixel those lists overflow, so such frames go straight to the per-lane traversal.
+    if (scene->d.has_bvh && !(f.flags & (INV_BRUTE_FORCE | INV_LANE_TRAVERSAL))) {
+        const double rect_px = (double)(f.rx1 - f.rx0) * (double)(f.ry1 - f.ry0);
+        if (rect_px > 0.0 && (double)scene->d.ntri * 64.0 / rect_px > 96.0) f.flags |= INV_LANE_TRAVERSAL;
+    }
     const bool brute = (params->flags & INV_BRUTE_FORCE) || !scene->d.has_bvh;
     if (brute)
         HIP_TRY(launch_render_brute(ctx->stream, f, scene->d, ao, dev));
