@@ -90,6 +90,10 @@ int inv_ctx_synchronize(inv_ctx* ctx);
  * has undefined behaviour there). */
 int inv_mesh_load_obj(const char* path, inv_mesh** out);
 int inv_mesh_parse_obj(const char* text, uint64_t size, inv_mesh** out);
+/* A second, tolerant reader for meshes that are not in that format (the TODOs at src/invert.cpp:24, 41): free-form
+ * numbers (correctly rounded, so NOT bit-identical to the loader above on the same text), `f` corners i, i/t, i//n,
+ * i/t/n, negative indices, polygons (fanned), CRLF, missing final newline; other line kinds are ignored. */
+int inv_mesh_load_obj_general(const char* path, inv_mesh** out);
 /* The arrays the draw binds (src/invert.cpp:826-827): float4-stride vertices (lane 3 ignored), u32 indices. */
 int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t nidx, inv_mesh** out);
 /* Obj::vertexDataSize / numIndices (src/invert.cpp:27-31, 77-79), in elements. */
@@ -138,6 +142,14 @@ int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_
  * 4 for every attachment.  Only enqueues. */
 int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, uint64_t rank_stride, void* frame,
                      uint32_t elem_size);
+
+/* ---- making the attachments inspectable (host buffers) ----------------------------------------------------------- */
+/* The reference presents its colour image (src/invert.cpp:674-683) and stores nothing.  Binary PPM (P6) of a colour
+ * buffer (pass INV_RGBA in `flags` if it was rendered with it), little-endian PFM of a depth buffer, and a raw
+ * uint32 dump of primitive ids behind a 16-byte header {"PID1", width, height, 0}. */
+int inv_write_ppm(const char* path, const void* color, uint32_t width, uint32_t height, uint32_t flags);
+int inv_write_pfm(const char* path, const float* depth, uint32_t width, uint32_t height);
+int inv_write_primid(const char* path, const uint32_t* primid, uint32_t width, uint32_t height);
 
 const char* inv_last_error(void);
 const char* inv_version(void);

@@ -20,11 +20,12 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEV
 # every symbol include/invert.h declares
 SYMBOLS = (
     "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize",
-    "inv_mesh_load_obj", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
+    "inv_mesh_load_obj", "inv_mesh_load_obj_general", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
     "inv_mesh_indices", "inv_mesh_destroy",
     "inv_camera_reference",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
     "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
+    "inv_write_ppm", "inv_write_pfm", "inv_write_primid",
     "inv_last_error", "inv_version",
 )
 
@@ -73,6 +74,10 @@ def lib():
     L.inv_ctx_destroy.argtypes = [vp]
     L.inv_ctx_synchronize.argtypes = [vp]
     L.inv_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.inv_mesh_load_obj_general.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.inv_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.inv_write_pfm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.inv_write_primid.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.inv_mesh_parse_obj.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(vp)]
     L.inv_mesh_from_arrays.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
     L.inv_mesh_counts.argtypes = [vp, u32p, u32p]
@@ -128,6 +133,13 @@ class Mesh:
         return Mesh(h)
 
     @staticmethod
+    def load_obj_general(path: str) -> "Mesh":
+        """Tolerant reader (free-form numbers, i/t/n corners, polygons, CRLF); not bit-identical to load_obj."""
+        h = C.c_void_p()
+        _chk(lib().inv_mesh_load_obj_general(os.fsencode(path), C.byref(h)))
+        return Mesh(h)
+
+    @staticmethod
     def parse_obj(text: bytes) -> "Mesh":
         h = C.c_void_p()
         _chk(lib().inv_mesh_parse_obj(text, len(text), C.byref(h)))
@@ -170,6 +182,24 @@ class Mesh:
             self.close()
         except Exception:
             pass
+
+
+def write_ppm(path: str, color: np.ndarray, flags: int = 0) -> None:
+    color = np.ascontiguousarray(color, np.uint8)
+    h, w = color.shape[:2]
+    _chk(lib().inv_write_ppm(os.fsencode(path), color.ctypes.data, w, h, flags))
+
+
+def write_pfm(path: str, depth: np.ndarray) -> None:
+    depth = np.ascontiguousarray(depth, np.float32)
+    h, w = depth.shape
+    _chk(lib().inv_write_pfm(os.fsencode(path), depth.ctypes.data, w, h))
+
+
+def write_primid(path: str, primid: np.ndarray) -> None:
+    primid = np.ascontiguousarray(primid, np.uint32)
+    h, w = primid.shape
+    _chk(lib().inv_write_primid(os.fsencode(path), primid.ctypes.data, w, h))
 
 
 class Context:

@@ -172,6 +172,30 @@ int inv_mesh_load_obj(const char* path, inv_mesh** out) {
     return inv_mesh_parse_obj(text.data(), text.size(), out);
 }
 
+int inv_mesh_load_obj_general(const char* path, inv_mesh** out) {
+    if (!out) return fail(INV_ERR_ARG, "inv_mesh_load_obj_general: out is null");
+    *out = nullptr;
+    if (!path) return fail(INV_ERR_ARG, "inv_mesh_load_obj_general: path is null");
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) return fail(INV_ERR_IO, std::string("inv_mesh_load_obj_general: cannot open ") + path);
+    std::vector<char> text;
+    char chunk[1 << 16]; // chunked reads (the TODO at src/invert.cpp:41)
+    size_t got;
+    while ((got = std::fread(chunk, 1, sizeof chunk, fp)) > 0) text.insert(text.end(), chunk, chunk + got);
+    bool bad = std::ferror(fp) != 0;
+    std::fclose(fp);
+    if (bad) return fail(INV_ERR_IO, std::string("inv_mesh_load_obj_general: read error on ") + path);
+    inv_mesh* m = new (std::nothrow) inv_mesh;
+    if (!m) return fail(INV_ERR_NOMEM, "inv_mesh_load_obj_general: out of memory");
+    int rc = parse_obj_general(text.data(), text.size(), m->xyzw, m->idx);
+    if (rc != INV_OK) {
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return INV_OK;
+}
+
 int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t nidx, inv_mesh** out) {
     if (!out) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: out is null");
     *out = nullptr;
@@ -429,6 +453,21 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return INV_OK;
+}
+
+int inv_write_ppm(const char* path, const void* color, uint32_t width, uint32_t height, uint32_t flags) {
+    if (!path || !color || !width || !height) return fail(INV_ERR_ARG, "inv_write_ppm: null argument or zero extent");
+    return write_ppm(path, (const uint8_t*)color, width, height, (flags & INV_RGBA) != 0);
+}
+
+int inv_write_pfm(const char* path, const float* depth, uint32_t width, uint32_t height) {
+    if (!path || !depth || !width || !height) return fail(INV_ERR_ARG, "inv_write_pfm: null argument or zero extent");
+    return write_pfm(path, depth, width, height);
+}
+
+int inv_write_primid(const char* path, const uint32_t* primid, uint32_t width, uint32_t height) {
+    if (!path || !primid || !width || !height) return fail(INV_ERR_ARG, "inv_write_primid: null argument or zero extent");
+    return write_primid(path, primid, width, height);
 }
 
 int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_ids, uint32_t tile_ids_cap,

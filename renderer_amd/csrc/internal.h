@@ -19,6 +19,12 @@ int fail(int code, const std::string& msg);
 // A1 -- obj_loader.cpp
 int parse_obj_text(const char* text, uint64_t size, std::vector<float>& xyzw, std::vector<uint32_t>& idx);
 
+// io_extras.cpp
+int parse_obj_general(const char* text, uint64_t size, std::vector<float>& xyzw, std::vector<uint32_t>& idx);
+int write_ppm(const char* path, const uint8_t* color, uint32_t w, uint32_t h, bool rgba_order);
+int write_pfm(const char* path, const float* depth, uint32_t w, uint32_t h);
+int write_primid(const char* path, const uint32_t* primid, uint32_t w, uint32_t h);
+
 // A2 -- camera.cpp
 void reference_camera(uint32_t width, uint32_t height, inv_camera* cam);
 // view*model, its inverse (double Gauss-Jordan rounded to float) and the Lambert light direction.

@@ -330,3 +330,23 @@ def test_instanced_scene_small(oracle, gpu_ctx, bunny_path, bunny_mesh, mode):
     if mode == 0:
         _check_lbvh(oracle, scene, fx, fi)
     scene.close()
+
+
+def test_mesh_from_the_general_reader_renders(oracle, gpu_ctx, tmp_path):
+    """A free-form OBJ with quads and i/t/n corners through the tolerant reader, rendered against the oracle."""
+    xyz, faces = objfmt.icosphere(2, radius=0.06, center=(0.0, 0.11, 0.0))
+    lines = ["v %r %r %r" % tuple(float(np.float32(c)) for c in p) for p in xyz]
+    lines += ["vn 0 0 1", "vt 0 0"]
+    lines += ["f %d/1/1 %d/1/1 %d/1/1" % tuple(int(i) + 1 for i in f) for f in faces]
+    path = tmp_path / "sphere.obj"
+    path.write_text("\r\n".join(lines))
+    mesh = R.Mesh.load_obj_general(str(path))
+    assert mesh.counts() == (len(xyz), faces.size)
+    scene = R.Scene(gpu_ctx, mesh)
+    w, h = 256, 256
+    prm = R.make_params(w, h, flags=R.LAMBERT, ao_rays=8)
+    got = scene.render(R.camera_reference(w, h), prm)
+    want = oracle.render_bvh(mesh.vertices, mesh.indices, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "icosphere")
+    assert (got[2] != 0xFFFFFFFF).sum() > 2000
+    scene.close()

@@ -157,3 +157,55 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".inc")) or fn == "Makefile":
                 text = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "liboracle" not in text and "oracle/" not in text and "import oracle" not in text, fn
+
+
+def test_general_obj_reader(tmp_path, bunny_path, bunny_mesh):
+    """Tolerant reader: same topology as the fixed-format loader on the bunny, coordinates = correctly rounded text."""
+    g = R.Mesh.load_obj_general(bunny_path)
+    xyzw, idx = bunny_mesh
+    assert g.counts() == (2503, 14904) and np.array_equal(g.indices, idx)
+    lines = [ln for ln in objfmt.bunny().text().decode().splitlines() if ln.startswith("v ")]
+    exact = np.array([[np.float32(float(t)) for t in ln.split()[1:]] for ln in lines], np.float32)
+    assert np.array_equal(g.vertices[:, :3].view(np.uint32), exact.view(np.uint32))
+    ulp = np.abs(g.vertices[:, :3].view(np.int32).astype(np.int64) - xyzw[:, :3].view(np.int32))
+    assert int(ulp.max()) == 3  # the reference loader's own arithmetic is up to 3 ulp away (src/invert.cpp:139-152)
+    text = (b"# comment\r\nmtllib x.mtl\r\no thing\r\nv 0 0 0\r\nv 1.5 0 0 1.0\r\nv 1 1e0 -2.5E-1\r\nv  0\t1 0\r\n"
+            b"vn 0 0 1\r\nvt 0.5 0.5\r\ns off\r\nf 1/1/1 2/1/1 3/1/1 4/1/1\r\nf -4//1 -3//1 -1//1\r\nf 1 3 4")  # no final newline
+    path = tmp_path / "general.obj"
+    path.write_bytes(text)
+    m = R.Mesh.load_obj_general(str(path))
+    assert m.counts() == (4, 12)
+    assert m.indices.tolist() == [0, 1, 2, 0, 2, 3, 0, 1, 3, 0, 2, 3]  # quad fanned, relative indices resolved
+    assert m.vertices[:, :3].tolist() == [[0, 0, 0], [1.5, 0, 0], [1, 1, -0.25], [0, 1, 0]]
+    for bad in (b"v 1 2\n", b"v 0 0 0\nf 1 2 3\n", b"v 0 0 0\nf 1 1\n", b"v 0 0 0\nf 0 1 1\n", b"v a b c\n"):
+        path.write_bytes(bad)
+        with pytest.raises(R.InvertError) as e:
+            R.Mesh.load_obj_general(str(path))
+        assert e.value.code == api.ERR_FORMAT
+    with pytest.raises(R.InvertError) as e:
+        R.Mesh.load_obj_general(str(tmp_path / "missing.obj"))
+    assert e.value.code == api.ERR_IO
+
+
+def test_image_writers(tmp_path):
+    color, depth, primid = common.golden_frame("bunny_512")
+    api.write_ppm(str(tmp_path / "c.ppm"), color)
+    api.write_pfm(str(tmp_path / "d.pfm"), depth)
+    api.write_primid(str(tmp_path / "p.bin"), primid)
+    raw = (tmp_path / "c.ppm").read_bytes()
+    head = b"P6\n512 512\n255\n"
+    assert raw.startswith(head) and len(raw) == len(head) + 512 * 512 * 3
+    rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(512, 512, 3)
+    assert np.array_equal(rgb, color[..., [2, 1, 0]])  # B,G,R,A in memory -> R,G,B in the file
+    api.write_ppm(str(tmp_path / "c2.ppm"), color[..., [2, 1, 0, 3]], flags=R.RGBA)
+    assert (tmp_path / "c2.ppm").read_bytes() == raw
+    raw = (tmp_path / "d.pfm").read_bytes()
+    head = b"Pf\n512 512\n-1.0\n"
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(512, 512)[::-1], depth)  # bottom row first
+    raw = (tmp_path / "p.bin").read_bytes()
+    assert raw[:4] == b"PID1" and np.frombuffer(raw[4:16], "<u4").tolist() == [512, 512, 0]
+    assert np.array_equal(np.frombuffer(raw[16:], "<u4").reshape(512, 512), primid)
+    with pytest.raises(R.InvertError) as e:
+        api.write_ppm(str(tmp_path / "nodir" / "x.ppm"), color)
+    assert e.value.code == api.ERR_IO
