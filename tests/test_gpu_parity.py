@@ -348,5 +348,5 @@ def test_mesh_from_the_general_reader_renders(oracle, gpu_ctx, tmp_path):
     got = scene.render(R.camera_reference(w, h), prm)
     want = oracle.render_bvh(mesh.vertices, mesh.indices, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
     common.assert_frames_equal(got, want, "icosphere")
-    assert (got[2] != 0xFFFFFFFF).sum() > 2000
+    assert (got[2] != 0xFFFFFFFF).sum() > 500
     scene.close()
