@@ -269,6 +269,8 @@ struct TileLds {
     float win_t[64];             // and its ray parameter
     uint32_t groups[kCutCap / kCutGroup]; // cut groups whose box meets the tile's frustum
     uint32_t n_groups;
+    Frustum fr;                  // the tile's four side planes, computed once by the first wave
+    float corner[4][4];          // directions through the grown tile's corners (facing test)
     uint32_t n_front[2];
     uint32_t n_ranges;
     uint32_t n_rec;
@@ -296,8 +298,19 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     constexpr uint32_t NT = NW * 64;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const float grow = 2.0f * f.pad;
-    const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u));
     if (f.flags & kDebugSkipAll) return;
+    if (wave == 0) { // tile constants once per workgroup instead of once per wave
+        const Frustum f0 = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u));
+        if (lane < 4) {
+            S.fr.p[lane] = f0.p[lane];
+            const float m = 0.0625f;
+            float dx, dy, dz;
+            dir_at(f, (lane & 1u) ? (float)(tx0 + 8u) + m : (float)tx0 - m, (lane & 2u) ? (float)(ty0 + 8u) + m : (float)ty0 - m,
+                   dx, dy, dz);
+            S.corner[lane][0] = dx, S.corner[lane][1] = dy, S.corner[lane][2] = dz;
+            S.corner[lane][3] = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+        }
+    }
     const bool stamps = (f.flags & kDebugCounts) && !(f.flags & kDebugSkipAfter2); // diagnostic build of the image
     unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
     if (stamps) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -308,6 +321,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     const float srgb_entry = kSrgbT[tid & 255u]; // stored to LDS later: the load stays in flight behind the first steps
     if (tid < 64) S.best[tid] = kMissKey;
     __syncthreads();
+    const Frustum fr = S.fr;
     const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
         const uint32_t g = base + tid;
@@ -417,11 +431,9 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     if (!S.overflow) {
         // directions through the four corners of the grown tile (for the facing test)
         float cdx[4], cdy[4], cdz[4];
-        const float m = 0.0625f;
-        dir_at(f, (float)tx0 - m, (float)ty0 - m, cdx[0], cdy[0], cdz[0]);
-        dir_at(f, (float)(tx0 + 8u) + m, (float)ty0 - m, cdx[1], cdy[1], cdz[1]);
-        dir_at(f, (float)tx0 - m, (float)(ty0 + 8u) + m, cdx[2], cdy[2], cdz[2]);
-        dir_at(f, (float)(tx0 + 8u) + m, (float)(ty0 + 8u) + m, cdx[3], cdy[3], cdz[3]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) cdx[c] = S.corner[c][0], cdy[c] = S.corner[c][1], cdz[c] = S.corner[c][2];
+        const float cmax = fmaxf(fmaxf(S.corner[0][3], S.corner[1][3]), fmaxf(S.corner[2][3], S.corner[3][3]));
         const uint32_t nslots = nranges * kRangeMax;
         for (uint32_t base = 0; base < nslots; base += NT) { // block-uniform trip count
             const uint32_t q = base + tid;
@@ -442,12 +454,11 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                     // combination of the corner directions: if det is clearly negative at all four corners the
                     // triangle faces away from every ray of the tile (cull BACK, src/invert.cpp:1334).
                     const float nx = C.y * B.z - C.z * B.y, ny = C.z * B.x - C.x * B.z, nz = C.x * B.y - C.y * B.x;
-                    float dmax = -INFINITY, scale = 0.0f;
+                    float dmax = -INFINITY;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        dmax = fmaxf(dmax, (cdx[c] * nx + cdy[c] * ny) + cdz[c] * nz);
-                        scale = fmaxf(scale, (fabsf(cdx[c] * nx) + fabsf(cdy[c] * ny)) + fabsf(cdz[c] * nz));
-                    }
+                    for (int c = 0; c < 4; c++) dmax = fmaxf(dmax, (cdx[c] * nx + cdy[c] * ny) + cdz[c] * nz);
+                    // bound on the magnitude of the terms the dot products are summed from
+                    const float scale = cmax * ((fabsf(nx) + fabsf(ny)) + fabsf(nz));
                     keep = keep && !(dmax < -1e-4f * scale);
                 }
             }
@@ -543,6 +554,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tiles_x, uint32_t ntiles,
                                                          uint32_t fill_blocks, uint32_t pixel_blocks, int vec4,
+                                                         uint32_t row4_magic,
                                                          const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                          const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                                          const float4* __restrict__ cut,
@@ -566,16 +578,20 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
     if (vec4) {
         // 16 bytes (four pixels of a row) per lane and attachment, grid-stride: 1 KiB per wave-instruction
         const uint32_t row4 = (f.nranks <= 1 ? f.w : f.tile) >> 2; // chunks per stored row
-        const uint64_t nchunks = f.npix >> 2;
+        const uint32_t nchunks = (uint32_t)(f.npix >> 2);          // the host keeps npix near 2^31 at most, so c + stride cannot wrap
         const uint4 c4 = make_uint4(bg, bg, bg, bg), p4 = make_uint4(~0u, ~0u, ~0u, ~0u);
         const float4 d4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        for (uint64_t c = (uint64_t)(blockIdx.x - ntiles) * NT + threadIdx.x; c < nchunks; c += (uint64_t)fill_blocks * NT) {
+        const uint32_t stride = fill_blocks * NT;
+        for (uint32_t c = (blockIdx.x - ntiles) * NT + threadIdx.x; c < nchunks; c += stride) {
             uint32_t px, py;
             if (f.nranks <= 1) {
-                px = (uint32_t)(c % row4) << 2, py = (uint32_t)(c / row4);
+                // c / row4 without a division: row4_magic = floor(2^32 / row4) gives the quotient or one less
+                uint32_t q = __umulhi(c, row4_magic), r = c - q * row4;
+                if (r >= row4) q++, r -= row4;
+                px = r << 2, py = q;
             } else {
                 const uint32_t per_tile = (f.tile * f.tile) >> 2;
-                const uint32_t slot = (uint32_t)(c / per_tile), rem = (uint32_t)(c % per_tile);
+                const uint32_t slot = c / per_tile, rem = c % per_tile;
                 const uint32_t id = slot * f.nranks + f.rank;
                 if (id >= f.ntiles) continue;
                 px = (id % f.tiles_x) * f.tile + ((rem % row4) << 2);
@@ -733,9 +749,11 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     const uint32_t nt = (uint32_t)nw * 64u;
     const uint64_t fill_work = vec4 ? ((f.npix >> 2) + nt - 1u) / nt : pixel_blocks;
     const uint32_t fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
+    const uint32_t row4 = std::max(1u, (f.nranks <= 1 ? f.w : f.tile) >> 2);
+    const uint32_t row4_magic = row4 == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / row4);
 #define INV_LAUNCH_TILE(NW)                                                                                          \
     hipLaunchKernelGGL(k_render_tile<NW>, dim3(ntiles + fill_blocks), dim3(NW * 64), 0, s, f, tiles_x, ntiles,       \
-                       fill_blocks, pixel_blocks, vec4, (const float4*)sc.triA, (const float4*)sc.triB,               \
+                       fill_blocks, pixel_blocks, vec4, row4_magic, (const float4*)sc.triA, (const float4*)sc.triB, \
                        (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,                        \
                        (const float4*)sc.cut_groups, sc.ncut, ao, out)
     if (nw == 8)

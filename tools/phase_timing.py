@@ -28,7 +28,11 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--flags", type=int, default=R.LAMBERT | R.INVERT)
+    ap.add_argument("--only", help="run a single variant (for counter passes under rocprofv3)")
     a = ap.parse_args()
+    global VARIANTS
+    if a.only:
+        VARIANTS = [v for v in VARIANTS if v[0] == a.only]
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = R.Context(0, stream=stream.cuda_stream)

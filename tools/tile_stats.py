@@ -48,6 +48,11 @@ def main():
     start = d[::8, 6::8][ys, xs].astype(np.int64)
     print("tile start spread: %.2f us; last tile end - first tile start: %.2f us" %
           ((start.max() - start.min()) / 100.0, ((start + real).max() - start.min()) / 100.0))
+    rel = (start - start.min()) / 100.0
+    print("start (us) by block index decile:", " ".join("%.2f" % rel[int(q * (len(rel) - 1) / 10)] for q in range(11)))
+    print("start (us) percentiles 0..100:   ", " ".join("%.2f" % v for v in np.percentile(rel, range(0, 101, 10))))
+    end = rel + real / 100.0
+    print("end   (us) percentiles 0..100:   ", " ".join("%.2f" % v for v in np.percentile(end, range(0, 101, 10))))
     i = int(np.argmax(t1 + t2 + t3))
     print("slowest tile: %d records, phases %d / %d / %d cycles" % (n[i], t1[i], t2[i], t3[i]))
     for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 256)):
