@@ -5,9 +5,10 @@
 
 One step = one frame of the workload rendered through the C ABI (include/invert.h) with every input
 (triangles, LBVH) and output buffer resident in HBM.  With N > 1 (launched by torch.distributed.run, one
-process per GPU) the frame's 64x64 screen tiles are dealt round-robin to the ranks, every rank renders its
-tiles, and the three attachments are gathered to rank 0 over RCCL and de-interleaved there; the same frame
-is rendered whatever N is, so scaling is "strong".
+process per GPU) 64x64 screen tiles are dealt round-robin to the ranks, every rank renders its tiles, and the
+three attachments are gathered to rank 0 over RCCL and put together there; the same frame is rendered whatever N
+is, so scaling is "strong".  --composite sparse (default) deals out only the tiles under the scene's projected
+bounds and rank 0 clears the rest of its frame itself; --composite dense deals out and gathers the whole frame.
 
 Rank 0 prints one JSON line with the contract fields plus
   roofline      -- the render kernel against the HBM roofline (algorithmic bytes = 12 B per pixel written +
@@ -100,6 +101,8 @@ def main():
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
+    ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
+                    help="N > 1: gather only the tiles that can contain hits (sparse) or the whole frame (dense)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on one GPU (ranks share cuda:0, gather through host memory)")
     args = ap.parse_args()
@@ -137,16 +140,23 @@ def main():
     ntri, nnodes, scene_bytes = scene.counts()
     cam = R.camera_reference(w, h)
     ao_rays = wl.get("ao_rays", 0)
-    prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
-    npix, _ = R.tile_layout(prm)
-    # one buffer, three planes (colour, depth, primitive id), 4 bytes per pixel each
-    planes = torch.empty(3, npix, dtype=torch.int32, device="cuda")
-    ptr = [planes[i].data_ptr() for i in range(3)]
-    gathered = frame = None
-    if world > 1 and rank == 0:
-        gathered = torch.empty(world, 3, npix, dtype=torch.int32, device="cuda")
-        frame = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
-    prm0 = R.make_params(w, h, tile=tile, nranks=world)
+    sparse = world > 1 and args.composite == "sparse"
+    gathered = frame = sc = None
+    if sparse:
+        sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=flags, ao_rays=ao_rays)
+        frame, gathered = sc.frame, sc.gathered
+        # pixels this rank's render launch writes
+        npix = sc.slot_elems if rank else w * h - (world - 1) * sc.slot_elems
+    else:
+        prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
+        npix, _ = R.tile_layout(prm)
+        # one buffer, three planes (colour, depth, primitive id), 4 bytes per pixel each
+        planes = torch.empty(3, npix, dtype=torch.int32, device="cuda")
+        ptr = [planes[i].data_ptr() for i in range(3)]
+        if world > 1 and rank == 0:
+            gathered = torch.empty(world, 3, npix, dtype=torch.int32, device="cuda")
+            frame = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
+        prm0 = R.make_params(w, h, tile=tile, nranks=world)
 
     # Render-kernel duration: with one GPU two HIP events bracket the K launches of the timed region (the stream
     # holds nothing else, so their distance / K is the average launch-to-launch time of the kernel; a pair of
@@ -162,10 +172,22 @@ def main():
         timed = world > 1 and i is not None and i % every == 0
         if timed:
             ev0[i // every].record(stream)
-        scene.render_device(cam, prm, ptr[0], ptr[1], ptr[2])
+        if sparse:
+            sc.render()
+        else:
+            scene.render_device(cam, prm, ptr[0], ptr[1], ptr[2])
         if timed:
             ev1[i // every].record(stream)
-        if world > 1:
+        if sparse:
+            if args.backend == "nccl":
+                sc.composite()
+            elif sc.slot_elems:  # rehearsal: the collective runs on host copies
+                stream.synchronize()
+                host = RD.gather_to_rank0(sc.planes.cpu(), rank, world)
+                if rank == 0:
+                    gathered.copy_(host)
+                sc.scatter_received()
+        elif world > 1:
             if args.backend == "nccl":
                 RD.gather_to_rank0(planes, rank, world, gathered)
             else:  # rehearsal: the collective runs on host copies
@@ -229,7 +251,8 @@ def main():
                        "width": w, "height": h, "spp": spp, "ao_rays": ao_rays, "hit_pixels": hit_pixels,
                        "rays_per_frame": rays_per_step, "flags": int(flags),
                        "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile,
-                       "parallelism": "tiles%%%d + RCCL gather to rank 0" % world if world > 1 else "1 GPU"},
+                       "parallelism": ("%s tiles %% %d + RCCL gather to rank 0" % (args.composite, world)
+                                       if world > 1 else "1 GPU")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
                          "kernel": ("k_render_brute" if args.brute_force else "k_render_tile") + ("+k_ao" if ao_rays else ""),

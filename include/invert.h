@@ -51,6 +51,7 @@ enum {
     INV_RGBA = 4u,        /* colour bytes R,G,B,A; default is B,G,R,A = VK_FORMAT_B8G8R8A8_SRGB memory order (src/invert.cpp:519) */
     INV_BRUTE_FORCE = 8u, /* test every triangle for every ray instead of traversing the LBVH */
     INV_LANE_TRAVERSAL = 16u, /* one lane per ray with a stack in LDS instead of the tile kernel's candidate lists */
+    INV_SPARSE = 32u,     /* with nranks > 1: deal out only the tiles that can contain hits (see inv_sparse_layout) */
 };
 
 /* What the reference fixes as literals or takes from the window: extent (src/invert.cpp:779-791),
@@ -142,6 +143,27 @@ int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_
  * 4 for every attachment.  Only enqueues. */
 int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathered, uint64_t rank_stride, void* frame,
                      uint32_t elem_size);
+
+/* Sparse composite (INV_SPARSE, nranks > 1).  No counterpart in the reference, which draws on one GPU.
+ * Only the tiles touched by the hit rectangle -- the pixel rectangle [x0, x1) x [y0, y1) outside which every pixel
+ * of this scene and camera is background -- are dealt out: tile j of that grid (row-major) goes to rank
+ * j % nranks, slot j / nranks.  Rank 0's outputs are the row-major frame: it renders its own tiles in place and
+ * clears every pixel outside the dealt tiles; ranks 1.. hold only their slots.  After gathering the slot buffers,
+ * rank 0 copies the other ranks' tiles into its frame with inv_deinterleave_sparse.  inv_render computes the same
+ * rectangle from the scene and camera on every rank. */
+int inv_scene_hit_rect(const inv_scene* scene, const inv_camera* cam, uint32_t width, uint32_t height,
+                       uint32_t rect[4]);
+/* Layout for params->rank given the hit rectangle (host arithmetic only): grid = {first tile x, first tile y,
+ * tiles across, tiles down}, npixels = elements per attachment of this rank's buffers, tile_ids = the frame tile
+ * ids (row-major over the whole frame) of its tiles in slot order. */
+int inv_sparse_layout(const inv_params* params, const uint32_t rect[4], uint32_t grid[4], uint64_t* npixels,
+                      uint32_t* tile_ids, uint32_t tile_ids_cap, uint32_t* ntiles);
+/* Rank 0 after the gather: `nplanes` attachments at once.  Attachment k of rank r starts at element
+ * r * rank_stride + k * plane_stride of `gathered` and at k * frame_plane_stride of `frame` (4-byte elements,
+ * device pointers).  Rank 0's own part of `gathered` is not read.  Only enqueues. */
+int inv_deinterleave_sparse(inv_ctx* ctx, const inv_params* params, const uint32_t rect[4], const void* gathered,
+                            uint64_t rank_stride, uint64_t plane_stride, uint32_t nplanes, void* frame,
+                            uint64_t frame_plane_stride);
 
 /* ---- making the attachments inspectable (host buffers) ----------------------------------------------------------- */
 /* The reference presents its colour image (src/invert.cpp:674-683) and stores nothing.  Binary PPM (P6) of a colour

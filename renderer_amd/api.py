@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinvert_hip.so")
 
-LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL = 1, 2, 4, 8, 16
+LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL, SPARSE = 1, 2, 4, 8, 16, 32
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(8)
 
 # every symbol include/invert.h declares
@@ -25,6 +25,7 @@ SYMBOLS = (
     "inv_camera_reference",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
     "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
+    "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
     "inv_write_ppm", "inv_write_pfm", "inv_write_primid",
     "inv_last_error", "inv_version",
 )
@@ -96,6 +97,11 @@ def lib():
     L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_tile_layout.argtypes = [C.POINTER(Params), u64p, u32p, C.c_uint32, u32p]
     L.inv_deinterleave.argtypes = [vp, C.POINTER(Params), vp, C.c_uint64, vp, C.c_uint32]
+    rect = C.POINTER(C.c_uint32 * 4)
+    L.inv_scene_hit_rect.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.c_uint32, rect]
+    L.inv_sparse_layout.argtypes = [C.POINTER(Params), rect, rect, u64p, u32p, C.c_uint32, u32p]
+    L.inv_deinterleave_sparse.argtypes = [vp, C.POINTER(Params), rect, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp,
+                                          C.c_uint64]
     _lib = L
     return L
 
@@ -218,6 +224,14 @@ class Context:
         _chk(lib().inv_deinterleave(self._h, C.byref(prm), C.c_void_p(gathered_ptr), rank_stride,
                                     C.c_void_p(frame_ptr), 4))
 
+    def deinterleave_sparse(self, prm: Params, rect, gathered_ptr: int, rank_stride: int, plane_stride: int,
+                            nplanes: int, frame_ptr: int, frame_plane_stride: int):
+        """Rank 0 of a sparse composite: copy the other ranks' tiles into the row-major frame (all planes at once)."""
+        r = (C.c_uint32 * 4)(*rect)
+        _chk(lib().inv_deinterleave_sparse(self._h, C.byref(prm), C.byref(r), C.c_void_p(gathered_ptr or None),
+                                           rank_stride, plane_stride, nplanes, C.c_void_p(frame_ptr),
+                                           frame_plane_stride))
+
     def close(self):
         if self._h:
             lib().inv_ctx_destroy(self._h)
@@ -232,6 +246,17 @@ def tile_layout(prm: Params):
     _chk(lib().inv_tile_layout(C.byref(prm), C.byref(npix), ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size,
                                C.byref(nt)))
     return npix.value, ids[:nt.value]
+
+
+def sparse_layout(prm: Params, rect):
+    """Sparse composite layout for prm.rank: (grid (gx0, gy0, tiles_x, tiles_y), elements per plane, frame tile ids)."""
+    r, grid = (C.c_uint32 * 4)(*rect), (C.c_uint32 * 4)()
+    npix, nt = C.c_uint64(), C.c_uint32()
+    _chk(lib().inv_sparse_layout(C.byref(prm), C.byref(r), C.byref(grid), C.byref(npix), None, 0, C.byref(nt)))
+    ids = np.zeros(max(nt.value, 1), np.uint32)
+    _chk(lib().inv_sparse_layout(C.byref(prm), C.byref(r), C.byref(grid), C.byref(npix),
+                                 ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size, C.byref(nt)))
+    return tuple(grid), npix.value, ids[:nt.value]
 
 
 class Scene:
@@ -263,6 +288,12 @@ class Scene:
                                        out["leaf_parent"].ctypes.data, out["box"].ctypes.data))
         return out
 
+    def hit_rect(self, cam: Camera, width: int, height: int):
+        """Pixel rectangle (x0, y0, x1, y1) outside which every pixel is background for this camera."""
+        r = (C.c_uint32 * 4)()
+        _chk(lib().inv_scene_hit_rect(self._h, C.byref(cam), width, height, C.byref(r)))
+        return tuple(r)
+
     def vertex_shader(self, cam: Camera):
         """vertexShader over the mesh (reference src/shader.slang:22-29): (clip [nv,4], colour [nv,3])."""
         clip = np.zeros((self.nv, 4), np.float32)
@@ -275,13 +306,17 @@ class Scene:
 
         With nranks > 1 the arrays are this rank's tile slots, shape [slots, tile, tile(,4)].
         """
-        npix, _ = tile_layout(prm)
+        sparse = (prm.flags & SPARSE) and (prm.nranks or 1) > 1
+        if sparse:
+            _, npix, _ = sparse_layout(prm, self.hit_rect(cam, prm.width, prm.height))
+        else:
+            npix, _ = tile_layout(prm)
         color = np.empty(npix * 4, np.uint8)
         depth = np.empty(npix, np.float32)
         primid = np.empty(npix, np.uint32)
         out = Outputs(color.ctypes.data, depth.ctypes.data, primid.ctypes.data, 0)
         _chk(lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(out)))
-        if (prm.nranks or 1) <= 1:
+        if (prm.nranks or 1) <= 1 or (sparse and prm.rank == 0):
             h, w = prm.height, prm.width
             return color.reshape(h, w, 4), depth.reshape(h, w), primid.reshape(h, w)
         t = prm.tile or 64

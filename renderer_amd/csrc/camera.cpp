@@ -188,6 +188,7 @@ void hit_rect(const FrameK& f, const float bbox[6], uint32_t rect[4]) {
     rect[0] = 0, rect[1] = 0, rect[2] = f.w, rect[3] = f.h;
     const double g = 4.0 * (double)f.pad;
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    int behind = 0; // corners at or behind the eye plane
     for (int corner = 0; corner < 8; corner++) {
         const double p[3] = {(corner & 1) ? (double)bbox[3] + g : (double)bbox[0] - g,
                              (corner & 2) ? (double)bbox[4] + g : (double)bbox[1] - g,
@@ -197,13 +198,20 @@ void hit_rect(const FrameK& f, const float bbox[6], uint32_t rect[4]) {
             v[r] = (double)f.mv[r * 4 + 0] * p[0] + (double)f.mv[r * 4 + 1] * p[1] + (double)f.mv[r * 4 + 2] * p[2] +
                    (double)f.mv[r * 4 + 3];
         const double wc = -v[2];
-        if (!(wc > 1e-9)) return;
+        if (!(wc > 1e-9)) {
+            behind++;
+            continue;
+        }
         const double sx = ((double)f.p00 * v[0] / wc + 1.0) * 0.5 * (double)f.w;
         const double sy = ((double)f.p11 * v[1] / wc + 1.0) * 0.5 * (double)f.h;
         xmin = std::fmin(xmin, sx), xmax = std::fmax(xmax, sx);
         ymin = std::fmin(ymin, sy), ymax = std::fmax(ymax, sy);
     }
-    if (!(xmin <= xmax) || !(ymin <= ymax)) return;
+    if (behind == 8) { // the whole box is behind the eye: a hit needs w_clip > 0
+        rect[2] = rect[3] = 0;
+        return;
+    }
+    if (behind != 0 || !(xmin <= xmax) || !(ymin <= ymax)) return; // box straddles the eye plane: no bound
     auto clampu = [](double v, double hi) { return (uint32_t)std::fmin(std::fmax(v, 0.0), hi); };
     rect[0] = clampu(std::floor(xmin) - 2.0, (double)f.w);
     rect[1] = clampu(std::floor(ymin) - 2.0, (double)f.h);

@@ -24,8 +24,13 @@ struct FrameK {
     uint32_t rx0, ry0, rx1, ry1; // pixel rectangle that can contain hits (projected scene bounds); rest is clear
     uint32_t w, h;
     uint32_t spp, flags, seed;
-    // tile sharding
-    uint32_t tile, rank, nranks, tiles_x, ntiles, slots; // slots = tiles stored per rank
+    // Tile sharding.  The shards are dealt from a grid of tiles_x * tiles_y tiles of tile * tile pixels whose first
+    // tile is (gx0, gy0) in tile units: the whole frame (dense), or only the tiles the hit rectangle touches
+    // (sparse).  Grid tile id belongs to rank id % nranks and is that rank's slot id / nranks.
+    uint32_t tile, rank, nranks, tiles_x, tiles_y, ntiles, slots; // slots = tiles stored per rank
+    uint32_t gx0, gy0;
+    uint32_t rowmajor; // outputs are a row-major width * height frame (one rank, or rank 0 of a sparse composite);
+                       // otherwise this rank's slots one after another, tile * tile pixels each
     uint64_t npix;                                       // pixels this launch covers
 };
 

@@ -85,10 +85,37 @@ int fill_layout(const inv_params& p, FrameK* f) {
     if (f->rank >= f->nranks) return fail(INV_ERR_ARG, "params: rank must be below nranks");
     if (f->tile > 1024u || (f->tile & 31u)) return fail(INV_ERR_ARG, "params: tile must be a multiple of 32, at most 1024");
     f->tiles_x = (p.width + f->tile - 1) / f->tile;
-    uint32_t tiles_y = (p.height + f->tile - 1) / f->tile;
-    f->ntiles = f->tiles_x * tiles_y;
+    f->tiles_y = (p.height + f->tile - 1) / f->tile;
+    f->gx0 = f->gy0 = 0;
+    f->ntiles = f->tiles_x * f->tiles_y;
     f->slots = (f->ntiles + f->nranks - 1) / f->nranks;
-    f->npix = f->nranks == 1 ? (uint64_t)p.width * p.height : (uint64_t)f->slots * f->tile * f->tile;
+    f->rowmajor = f->nranks == 1;
+    f->npix = f->rowmajor ? (uint64_t)p.width * p.height : (uint64_t)f->slots * f->tile * f->tile;
+    return INV_OK;
+}
+
+// Sparse sharding (INV_SPARSE with several ranks): only the tiles the hit rectangle touches are dealt out; rank 0
+// holds the row-major frame and clears everything else itself.
+void apply_sparse_grid(const uint32_t rect[4], FrameK* f) {
+    if (f->nranks <= 1) return;
+    const uint32_t T = f->tile;
+    if (rect[2] > rect[0] && rect[3] > rect[1]) {
+        f->gx0 = rect[0] / T, f->gy0 = rect[1] / T;
+        f->tiles_x = (rect[2] + T - 1) / T - f->gx0;
+        f->tiles_y = (rect[3] + T - 1) / T - f->gy0;
+    } else {
+        f->gx0 = f->gy0 = f->tiles_x = f->tiles_y = 0;
+    }
+    f->ntiles = f->tiles_x * f->tiles_y;
+    f->slots = (f->ntiles + f->nranks - 1) / f->nranks;
+    f->rowmajor = f->rank == 0;
+    f->npix = f->rowmajor ? (uint64_t)f->w * f->h : (uint64_t)f->slots * T * T;
+}
+
+int check_rect(const uint32_t rect[4], uint32_t w, uint32_t h, const char* who) {
+    if (!rect) return fail(INV_ERR_ARG, std::string(who) + ": rect is null");
+    if (rect[0] > rect[2] || rect[1] > rect[3] || rect[2] > w || rect[3] > h)
+        return fail(INV_ERR_ARG, std::string(who) + ": rect must satisfy x0 <= x1 <= width and y0 <= y1 <= height");
     return INV_OK;
 }
 
@@ -404,6 +431,7 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
         uint32_t rect[4] = {0, 0, f.w, f.h};
         if (scene->d.has_bvh) hit_rect(f, scene->d.bbox, rect);
         f.rx0 = rect[0], f.ry0 = rect[1], f.rx1 = rect[2], f.ry1 = rect[3];
+        if (f.flags & INV_SPARSE) apply_sparse_grid(rect, &f);
     }
     HIP_TRY(hipSetDevice(ctx->device));
     Outputs dev = {nullptr, nullptr, nullptr};
@@ -486,6 +514,71 @@ int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_
         count++;
     }
     if (ntiles) *ntiles = count;
+    return INV_OK;
+}
+
+int inv_scene_hit_rect(const inv_scene* scene, const inv_camera* cam, uint32_t width, uint32_t height,
+                       uint32_t rect[4]) {
+    if (!scene || !cam || !rect) return fail(INV_ERR_ARG, "inv_scene_hit_rect: null argument");
+    inv_params p;
+    std::memset(&p, 0, sizeof p);
+    p.width = width, p.height = height;
+    FrameK f;
+    std::memset(&f, 0, sizeof f);
+    int rc = fill_layout(p, &f);
+    if (rc != INV_OK) return rc;
+    if ((rc = frame_from_camera(*cam, scene->max_abs, &f)) != INV_OK) return rc;
+    rect[0] = 0, rect[1] = 0, rect[2] = f.w, rect[3] = f.h;
+    if (scene->d.has_bvh) hit_rect(f, scene->d.bbox, rect);
+    return INV_OK;
+}
+
+int inv_sparse_layout(const inv_params* params, const uint32_t rect[4], uint32_t grid[4], uint64_t* npixels,
+                      uint32_t* tile_ids, uint32_t tile_ids_cap, uint32_t* ntiles) {
+    if (!params) return fail(INV_ERR_ARG, "inv_sparse_layout: params is null");
+    FrameK f;
+    std::memset(&f, 0, sizeof f);
+    int rc = fill_layout(*params, &f);
+    if (rc != INV_OK) return rc;
+    if ((rc = check_rect(rect, f.w, f.h, "inv_sparse_layout")) != INV_OK) return rc;
+    const uint32_t frame_tiles_x = f.tiles_x;
+    if (f.nranks <= 1) return fail(INV_ERR_ARG, "inv_sparse_layout: the sparse composite needs at least two ranks");
+    apply_sparse_grid(rect, &f);
+    if (grid) grid[0] = f.gx0, grid[1] = f.gy0, grid[2] = f.tiles_x, grid[3] = f.tiles_y;
+    if (npixels) *npixels = f.npix;
+    uint32_t count = 0;
+    for (uint32_t id = f.rank; id < f.ntiles; id += f.nranks) {
+        if (tile_ids && count < tile_ids_cap)
+            tile_ids[count] = (f.gy0 + id / f.tiles_x) * frame_tiles_x + f.gx0 + id % f.tiles_x;
+        count++;
+    }
+    if (ntiles) *ntiles = count;
+    return INV_OK;
+}
+
+int inv_deinterleave_sparse(inv_ctx* ctx, const inv_params* params, const uint32_t rect[4], const void* gathered,
+                            uint64_t rank_stride, uint64_t plane_stride, uint32_t nplanes, void* frame,
+                            uint64_t frame_plane_stride) {
+    if (!ctx || !params || !frame) return fail(INV_ERR_ARG, "inv_deinterleave_sparse: null argument");
+    FrameK f;
+    std::memset(&f, 0, sizeof f);
+    inv_params p = *params;
+    p.rank = 0;
+    int rc = fill_layout(p, &f);
+    if (rc != INV_OK) return rc;
+    if ((rc = check_rect(rect, f.w, f.h, "inv_deinterleave_sparse")) != INV_OK) return rc;
+    if (f.nranks <= 1) return fail(INV_ERR_ARG, "inv_deinterleave_sparse: the sparse composite needs at least two ranks");
+    apply_sparse_grid(rect, &f);
+    if (f.ntiles == 0 || nplanes == 0) return INV_OK; // nothing was dealt out: rank 0 already holds the frame
+    if (!gathered) return fail(INV_ERR_ARG, "inv_deinterleave_sparse: gathered is null");
+    const uint64_t own = (uint64_t)f.slots * f.tile * f.tile;
+    if (plane_stride < own || rank_stride < plane_stride * (nplanes - 1) + own)
+        return fail(INV_ERR_ARG, "inv_deinterleave_sparse: strides are smaller than one rank's planes");
+    if (frame_plane_stride < (uint64_t)f.w * f.h)
+        return fail(INV_ERR_ARG, "inv_deinterleave_sparse: frame_plane_stride is smaller than the frame");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_deinterleave_sparse(ctx->stream, f, (const uint32_t*)gathered, rank_stride, plane_stride, nplanes,
+                                       (uint32_t*)frame, frame_plane_stride));
     return INV_OK;
 }
 

@@ -67,6 +67,9 @@ hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 // Occlusion pass over the records the primary kernel queued (ao.rays > 0).
 hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
+hipError_t launch_deinterleave_sparse(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
+                                      uint64_t plane_stride, uint32_t nplanes, uint32_t* frame,
+                                      uint64_t frame_plane_stride);
 hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
                                uint32_t* frame);
 // LBVH build over triA/B/C (reorders them into Morton order); scratch is allocated and freed inside.

@@ -139,6 +139,35 @@ __global__ __launch_bounds__(256) void k_deinterleave(FrameK f, const uint32_t* 
     frame[i] = gathered[src];
 }
 
+// Sparse composite: only the grid tiles dealt to ranks 1.. are copied; rank 0 rendered the rest in place.
+__global__ __launch_bounds__(256) void k_deinterleave_sparse(FrameK f, const uint32_t* __restrict__ gathered,
+                                                             uint64_t rank_stride, uint64_t plane_stride,
+                                                             uint32_t nplanes, uint32_t* __restrict__ frame,
+                                                             uint64_t frame_plane_stride) {
+    const uint32_t tt = f.tile * f.tile;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)f.ntiles * tt) return;
+    const uint32_t id = (uint32_t)(i / tt), rem = (uint32_t)(i % tt);
+    const uint32_t r = id % f.nranks;
+    if (r == 0) return;
+    const uint32_t px = (f.gx0 + id % f.tiles_x) * f.tile + rem % f.tile;
+    const uint32_t py = (f.gy0 + id / f.tiles_x) * f.tile + rem / f.tile;
+    if (px >= f.w || py >= f.h) return;
+    const uint64_t src = (uint64_t)r * rank_stride + (uint64_t)(id / f.nranks) * tt + rem;
+    const uint64_t dst = (uint64_t)py * f.w + px;
+    for (uint32_t k = 0; k < nplanes; k++) frame[k * frame_plane_stride + dst] = gathered[src + k * plane_stride];
+}
+
+hipError_t launch_deinterleave_sparse(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
+                                      uint64_t plane_stride, uint32_t nplanes, uint32_t* frame,
+                                      uint64_t frame_plane_stride) {
+    const uint64_t n = (uint64_t)f.ntiles * f.tile * f.tile;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_deinterleave_sparse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f, gathered,
+                       rank_stride, plane_stride, nplanes, frame, frame_plane_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
                                uint32_t* frame) {
     uint64_t n = (uint64_t)f.w * f.h;

@@ -319,21 +319,36 @@ __device__ __forceinline__ void finish_pixel(const FrameK& f, const AoK& ao, con
     }
 }
 
-// Work item -> pixel.  One rank: row-major.  Several ranks: this rank owns the
-// tiles with id % nranks == rank and stores them one after another, tile*tile
-// pixels each (partial edge tiles keep their full slot).
+// Grid tile of a pixel; false when the pixel lies outside the tile grid the shards are dealt from.
+__device__ __forceinline__ bool grid_tile(const FrameK& f, uint32_t px, uint32_t py, uint32_t& id) {
+    const uint32_t tx = px / f.tile - f.gx0, ty = py / f.tile - f.gy0; // wrap to huge values left of / above the grid
+    id = ty * f.tiles_x + tx;
+    return tx < f.tiles_x && ty < f.tiles_y;
+}
+
+// Row-major frame shared with other ranks (rank 0 of a sparse composite): this rank renders everything except
+// the grid tiles dealt to the others.
+__device__ __forceinline__ bool owns_rowmajor(const FrameK& f, uint32_t px, uint32_t py) {
+    if (f.nranks <= 1) return true;
+    uint32_t id;
+    return !grid_tile(f, px, py, id) || id % f.nranks == f.rank;
+}
+
+// Work item -> pixel.  Row-major frames: item = pixel.  Slot buffers: this rank owns the grid tiles with
+// id % nranks == rank and stores them one after another, tile*tile pixels each (partial edge tiles keep their
+// full slot).
 __device__ __forceinline__ bool work_to_pixel(const FrameK& f, uint64_t i, uint32_t& px, uint32_t& py) {
-    if (f.nranks <= 1) {
+    if (f.rowmajor) {
         px = (uint32_t)(i % f.w);
         py = (uint32_t)(i / f.w);
-        return true;
+        return owns_rowmajor(f, px, py);
     }
     uint32_t tt = f.tile * f.tile;
     uint32_t slot = (uint32_t)(i / tt), rem = (uint32_t)(i % tt);
     uint32_t id = slot * f.nranks + f.rank;
     if (id >= f.ntiles) return false;
-    px = (id % f.tiles_x) * f.tile + rem % f.tile;
-    py = (id / f.tiles_x) * f.tile + rem / f.tile;
+    px = (f.gx0 + id % f.tiles_x) * f.tile + rem % f.tile;
+    py = (f.gy0 + id / f.tiles_x) * f.tile + rem / f.tile;
     return px < f.w && py < f.h;
 }
 

@@ -56,19 +56,19 @@ struct BlockOrigin {
 
 __device__ __forceinline__ BlockOrigin block_origin(const FrameK& f, uint32_t b) {
     BlockOrigin o;
-    if (f.nranks <= 1) {
+    if (f.rowmajor) {
         const uint32_t bx = (f.w + 31u) >> 5;
         o.x0 = (b % bx) * 32u, o.y0 = (b / bx) * 8u;
         o.out0 = (uint64_t)o.y0 * f.w + o.x0;
         o.pitch = f.w;
-        o.live = true;
+        o.live = owns_rowmajor(f, o.x0, o.y0); // a 32x8 block lies in one tile (tile is a multiple of 32)
     } else {
         const uint32_t perx = f.tile >> 5, pery = f.tile >> 3, bpt = perx * pery;
         const uint32_t slot = b / bpt, sub = b % bpt;
         const uint32_t id = slot * f.nranks + f.rank;
         const uint32_t tx = (sub % perx) * 32u, ty = (sub / perx) * 8u;
-        o.x0 = (id % f.tiles_x) * f.tile + tx;
-        o.y0 = (id / f.tiles_x) * f.tile + ty;
+        o.x0 = (f.gx0 + id % f.tiles_x) * f.tile + tx;
+        o.y0 = (f.gy0 + id / f.tiles_x) * f.tile + ty;
         o.out0 = (uint64_t)slot * f.tile * f.tile + (uint64_t)ty * f.tile + tx;
         o.pitch = f.tile;
         o.live = id < f.ntiles;
@@ -81,19 +81,19 @@ __device__ __forceinline__ BlockMap map_block16(const FrameK& f, uint32_t b, uin
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u), ly = ((wave >> 1) << 3) | (lane >> 3);
     BlockMap m;
-    if (f.nranks <= 1) {
+    if (f.rowmajor) {
         const uint32_t bx = (f.w + 15u) >> 4;
         m.px = (b % bx) * 16u + lx;
         m.py = (b / bx) * 16u + ly;
-        m.valid = m.px < f.w && m.py < f.h;
+        m.valid = m.px < f.w && m.py < f.h && owns_rowmajor(f, m.px, m.py);
         m.out = (uint64_t)m.py * f.w + m.px;
     } else {
         const uint32_t per = f.tile >> 4, bpt = per * per;
         const uint32_t slot = b / bpt, sub = b % bpt;
         const uint32_t id = slot * f.nranks + f.rank;
         const uint32_t tx = (sub % per) * 16u + lx, ty = (sub / per) * 16u + ly;
-        m.px = (id % f.tiles_x) * f.tile + tx;
-        m.py = (id / f.tiles_x) * f.tile + ty;
+        m.px = (f.gx0 + id % f.tiles_x) * f.tile + tx;
+        m.py = (f.gy0 + id / f.tiles_x) * f.tile + ty;
         m.valid = id < f.ntiles && m.px < f.w && m.py < f.h;
         m.out = (uint64_t)slot * f.tile * f.tile + (uint64_t)ty * f.tile + tx;
     }
@@ -244,11 +244,12 @@ __device__ __forceinline__ void dir_at(const FrameK& f, float x, float y, float&
 
 // output index of frame pixel (px, py); false if another rank owns it
 __device__ __forceinline__ bool out_index(const FrameK& f, uint32_t px, uint32_t py, uint64_t& idx) {
-    if (f.nranks <= 1) {
+    if (f.rowmajor) {
         idx = (uint64_t)py * f.w + px;
-        return true;
+        return owns_rowmajor(f, px, py);
     }
-    const uint32_t id = (py / f.tile) * f.tiles_x + px / f.tile;
+    uint32_t id;
+    if (!grid_tile(f, px, py, id)) return false;
     idx = (uint64_t)(id / f.nranks) * f.tile * f.tile + (uint64_t)(py % f.tile) * f.tile + px % f.tile;
     return id % f.nranks == f.rank;
 }
@@ -577,14 +578,14 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
     const uint32_t bg = background_pixel(f.flags);
     if (vec4) {
         // 16 bytes (four pixels of a row) per lane and attachment, grid-stride: 1 KiB per wave-instruction
-        const uint32_t row4 = (f.nranks <= 1 ? f.w : f.tile) >> 2; // chunks per stored row
+        const uint32_t row4 = (f.rowmajor ? f.w : f.tile) >> 2; // chunks per stored row
         const uint32_t nchunks = (uint32_t)(f.npix >> 2);          // the host keeps npix near 2^31 at most, so c + stride cannot wrap
         const uint4 c4 = make_uint4(bg, bg, bg, bg), p4 = make_uint4(~0u, ~0u, ~0u, ~0u);
         const float4 d4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         const uint32_t stride = fill_blocks * NT;
         for (uint32_t c = (blockIdx.x - ntiles) * NT + threadIdx.x; c < nchunks; c += stride) {
             uint32_t px, py;
-            if (f.nranks <= 1) {
+            if (f.rowmajor) {
                 // c / row4 without a division: row4_magic = floor(2^32 / row4) gives the quotient or one less
                 uint32_t q = __umulhi(c, row4_magic), r = c - q * row4;
                 if (r >= row4) q++, r -= row4;
@@ -594,8 +595,8 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
                 const uint32_t slot = c / per_tile, rem = c % per_tile;
                 const uint32_t id = slot * f.nranks + f.rank;
                 if (id >= f.ntiles) continue;
-                px = (id % f.tiles_x) * f.tile + ((rem % row4) << 2);
-                py = (id / f.tiles_x) * f.tile + rem / row4;
+                px = (f.gx0 + id % f.tiles_x) * f.tile + ((rem % row4) << 2);
+                py = (f.gy0 + id / f.tiles_x) * f.tile + rem / row4;
                 if (px >= f.w || py >= f.h) continue;
             }
             if (px >= hx0 && px < hx1 && py >= hy0 && py < hy1) continue; // traced by the first part of the grid
@@ -722,7 +723,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     if (!sc.has_bvh || sc.height > (uint32_t)kStack) return launch_render_brute(s, f, sc, ao, out);
     if (f.flags & INV_LANE_TRAVERSAL) {
         uint32_t blocks;
-        if (f.nranks <= 1) {
+        if (f.rowmajor) {
             blocks = ((f.w + 15u) >> 4) * ((f.h + 15u) >> 4);
         } else {
             const uint32_t per = f.tile >> 4;
@@ -733,7 +734,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         return hipGetLastError();
     }
     uint32_t pixel_blocks;
-    if (f.nranks <= 1)
+    if (f.rowmajor)
         pixel_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
     else
         pixel_blocks = f.slots * (f.tile >> 5) * (f.tile >> 3);
@@ -749,7 +750,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     const uint32_t nt = (uint32_t)nw * 64u;
     const uint64_t fill_work = vec4 ? ((f.npix >> 2) + nt - 1u) / nt : pixel_blocks;
     const uint32_t fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
-    const uint32_t row4 = std::max(1u, (f.nranks <= 1 ? f.w : f.tile) >> 2);
+    const uint32_t row4 = std::max(1u, (f.rowmajor ? f.w : f.tile) >> 2);
     const uint32_t row4_magic = row4 == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / row4);
 #define INV_LAUNCH_TILE(NW)                                                                                          \
     hipLaunchKernelGGL(k_render_tile<NW>, dim3(ntiles + fill_blocks), dim3(NW * 64), 0, s, f, tiles_x, ntiles,       \

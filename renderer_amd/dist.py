@@ -2,8 +2,14 @@
 
 Pixels are independent and the scene is replicated (every rank builds the same deterministic LBVH), so the only
 exchange is the final composite: each rank's tile-major planes go to rank 0 in one gather, and rank 0 scatters them
-into the row-major frame (inv_deinterleave on the GPU).  Works with the `nccl` (= RCCL) backend on device tensors
-and with `gloo` on host tensors (used by the CPU tests).
+into the row-major frame on the GPU.  Two layouts:
+
+  dense   every tile of the frame is dealt out (tile_id % world); rank 0 receives the whole frame.
+  sparse  only the tiles the scene's projected bounds touch are dealt out; rank 0 keeps the row-major frame,
+          clears the rest itself and receives just the other ranks' hit tiles (a few hundred KB instead of the
+          frame: xGMI into one GPU is an order of magnitude slower than that GPU's HBM).
+
+Works with the `nccl` (= RCCL) backend on device tensors and with `gloo` on host tensors (used by the CPU tests).
 """
 from __future__ import annotations
 
@@ -42,3 +48,57 @@ def deinterleave_on_gpu(ctx: api.Context, prm0: api.Params, gathered: torch.Tens
     npix = gathered.shape[2]
     for k in range(3):  # plane k of rank r starts at gathered[r, k]: ranks are 3 * npix elements apart
         ctx.deinterleave(prm0, gathered[0, k].data_ptr(), frame[k].data_ptr(), rank_stride=3 * npix)
+
+
+class SparseComposite:
+    """Buffers and steps of the sparse composite for one rank, one camera and one frame size.
+
+        sc = SparseComposite(scene, cam, width, height, rank, world, flags=..., spp=...)
+        sc.render()            # every rank: enqueue the draw of its share
+        sc.composite()         # every rank: the gather; rank 0 also copies the received tiles into sc.frame
+        sc.frame               # rank 0: [3, h*w] int32 planes (colour, depth bits, primitive id); None elsewhere
+    """
+
+    def __init__(self, scene: api.Scene, cam: api.Camera, width: int, height: int, rank: int, world: int,
+                 tile: int = 64, device="cuda", **params):
+        if world < 2:
+            raise ValueError("the sparse composite needs at least two ranks")
+        self.scene, self.cam, self.rank, self.world = scene, cam, rank, world
+        flags = params.pop("flags", 0) | api.SPARSE
+        self.prm = api.make_params(width, height, tile=tile, rank=rank, nranks=world, flags=flags, **params)
+        self.prm0 = api.make_params(width, height, tile=tile, rank=0, nranks=world, flags=flags)
+        self.rect = scene.hit_rect(cam, width, height)
+        # every rank > 0 holds the same number of slots; rank 0 sends a dummy of that size (a gather wants equal parts)
+        other = api.make_params(width, height, tile=tile, rank=1, nranks=world, flags=flags)
+        self.grid, self.slot_elems, _ = api.sparse_layout(other, self.rect)
+        self.frame = self.gathered = None
+        if rank == 0:
+            self.frame = torch.empty(3, width * height, dtype=torch.int32, device=device)
+            self.gathered = torch.empty(world, 3, self.slot_elems, dtype=torch.int32, device=device)
+            self.planes = self.gathered[0]  # rank 0's own (unused) part of the gather
+            self._out = self.frame
+        else:
+            self.planes = torch.empty(3, self.slot_elems, dtype=torch.int32, device=device)
+            self._out = self.planes
+
+    def render(self):
+        o = self._out
+        self.scene.render_device(self.cam, self.prm, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+
+    def gather(self):
+        if self.slot_elems == 0:
+            return  # nothing on screen: rank 0's frame is already complete
+        if self.rank == 0:
+            dist.gather(self.planes, list(self.gathered.unbind(0)), dst=0)
+        else:
+            dist.gather(self.planes, None, dst=0)
+
+    def scatter_received(self):
+        if self.rank == 0 and self.slot_elems:
+            n = self.slot_elems
+            self.scene.ctx.deinterleave_sparse(self.prm0, self.rect, self.gathered.data_ptr(), 3 * n, n, 3,
+                                               self.frame.data_ptr(), self.frame.shape[1])
+
+    def composite(self):
+        self.gather()
+        self.scatter_received()

@@ -85,3 +85,85 @@ def test_every_tile_has_exactly_one_owner():
     hit_tiles = [ty * 30 + tx for ty in range(301 // 64, 496 // 64 + 1) for tx in range(880 // 64, 1085 // 64 + 1)]
     per_rank = np.bincount([t % 8 for t in hit_tiles], minlength=8)
     assert per_rank.max() <= 3 and per_rank.min() >= 1
+
+
+# ---- sparse composite: only the tiles under the scene's projected bounds travel ------------------------------
+
+BUNNY_RECT_512 = (200, 130, 320, 260)  # a rectangle around the bunny's footprint in the 512x512 golden
+
+
+def _sparse_worker(rank, world, port, w, h, tile, rect, result_path):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    color, depth, primid = common.golden_frame("bunny_512")
+    full = [np.ascontiguousarray(color).view(np.uint32).reshape(512, 512)[:h, :w],
+            depth.view(np.uint32)[:h, :w], primid[:h, :w]]
+    prm = R.make_params(w, h, tile=tile, rank=rank, nranks=world, flags=R.SPARSE)
+    grid, npix, ids = R.sparse_layout(prm, rect)
+    _, slot_elems, _ = R.sparse_layout(R.make_params(w, h, tile=tile, rank=1, nranks=world, flags=R.SPARSE), rect)
+    tiles_x = (w + tile - 1) // tile
+    planes = torch.zeros(3, slot_elems, dtype=torch.int32)
+    if rank > 0:  # what this rank would have rendered: its tiles cut out of the full frame
+        assert npix == slot_elems
+        for k in range(3):
+            slots = np.zeros((slot_elems // (tile * tile), tile, tile), np.uint32)
+            for slot, tid in enumerate(ids):
+                ty, tx = divmod(int(tid), tiles_x)
+                part = full[k][ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
+                slots[slot, :part.shape[0], :part.shape[1]] = part
+            planes[k] = torch.from_numpy(slots.reshape(-1).view(np.int32))
+    ok = True
+    if rank == 0:
+        assert npix == w * h
+        gathered = torch.zeros(world, 3, slot_elems, dtype=torch.int32)
+        dist.gather(planes, list(gathered.unbind(0)), dst=0)
+        g = gathered.numpy().view(np.uint32)
+        for k in range(3):
+            frame = full[k].copy()
+            # rank 0 renders everything but the other ranks' tiles: blank those, then fill them from the gather
+            for j in range(grid[2] * grid[3]):
+                r, slot = j % world, j // world
+                if r == 0:
+                    continue
+                ty, tx = grid[1] + j // grid[2], grid[0] + j % grid[2]
+                y1, x1 = min((ty + 1) * tile, h), min((tx + 1) * tile, w)
+                frame[ty * tile:y1, tx * tile:x1] = 0xDEADBEEF
+                frame[ty * tile:y1, tx * tile:x1] = g[r, k].reshape(-1, tile, tile)[slot][:y1 - ty * tile, :x1 - tx * tile]
+            ok = ok and np.array_equal(frame, full[k])
+        with open(result_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    else:
+        dist.gather(planes, None, dst=0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,tile", [(2, 512, 512, 64), (3, 500, 300, 32)])
+def test_sparse_tiles_gather_to_rank0(tmp_path, world, w, h, tile):
+    result = str(tmp_path / "result.txt")
+    mp.spawn(_sparse_worker, args=(world, _free_port(), w, h, tile, BUNNY_RECT_512, result), nprocs=world, join=True)
+    assert open(result).read() == "ok"
+
+
+def test_sparse_layout_deals_each_grid_tile_once():
+    w, h, tile = 1920, 1080, 64
+    rect = (880, 301, 1086, 497)  # the bunny's footprint at 1080p
+    for world in (2, 4, 8):
+        seen, slot_elems = [], None
+        for r in range(world):
+            grid, npix, ids = R.sparse_layout(R.make_params(w, h, tile=tile, rank=r, nranks=world, flags=R.SPARSE), rect)
+            assert grid == (13, 4, 4, 4)
+            if r == 0:
+                assert npix == w * h
+            else:
+                assert npix == -(-16 // world) * tile * tile
+            seen += [int(i) for i in ids]
+        want = sorted((4 + ty) * 30 + 13 + tx for ty in range(4) for tx in range(4))
+        assert sorted(seen) == want
+    # an empty rectangle deals nothing
+    grid, npix, ids = R.sparse_layout(R.make_params(w, h, rank=1, nranks=2, flags=R.SPARSE), (0, 0, 0, 0))
+    assert grid[2] * grid[3] == 0 and npix == 0 and len(ids) == 0
+    with pytest.raises(R.InvertError):
+        R.sparse_layout(R.make_params(w, h, rank=0, nranks=2), (10, 10, 5, 20))
+    with pytest.raises(R.InvertError):
+        R.sparse_layout(R.make_params(w, h), rect)  # one rank: nothing to composite

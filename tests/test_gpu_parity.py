@@ -161,6 +161,64 @@ def test_tile_sharding_and_deinterleave(bunny_scene, gpu_ctx, nranks, tile):
     assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full[2])
 
 
+def _sparse_composite_single_gpu(scene, ctx, cam, w, h, nranks, tile, **kw):
+    """The sparse composite with the ranks played one after another on this GPU: rank 0 renders into the frame,
+    the other ranks' slot buffers are laid out as the gather would deliver them, inv_deinterleave_sparse finishes."""
+    import torch
+    flags = kw.pop("flags", 0) | R.SPARSE
+    rect = scene.hit_rect(cam, w, h)
+    prm = [R.make_params(w, h, flags=flags, tile=tile, rank=r, nranks=nranks, **kw) for r in range(nranks)]
+    grid, n, _ = R.sparse_layout(prm[1], rect)
+    frame = torch.full((3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    gathered = torch.full((nranks, 3, max(n, 1)), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
+    for r in range(nranks):
+        o = frame if r == 0 else gathered[r]
+        scene.render_device(cam, prm[r], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    ctx.deinterleave_sparse(prm[0], rect, gathered.data_ptr(), 3 * max(n, 1), max(n, 1), 3, frame.data_ptr(), h * w)
+    ctx.synchronize()
+    f = frame.cpu().numpy()
+    return (f[0].view(np.uint8).reshape(h, w, 4), f[1].view(np.float32).reshape(h, w),
+            f[2].view(np.uint32).reshape(h, w)), rect, grid, n
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("nranks,tile,w,h", [(2, 64, 1920, 1080), (8, 64, 1920, 1080), (3, 32, 500, 301), (4, 64, 333, 250)])
+def test_sparse_composite_equals_single_rank_frame(bunny_scene, gpu_ctx, mode, nranks, tile, w, h):
+    """Only the tiles under the projected scene bounds are dealt out; the composite is the single-rank frame."""
+    cam = R.camera_reference(w, h)
+    flags = R.LAMBERT | R.INVERT | mode
+    full = bunny_scene.render(cam, R.make_params(w, h, flags=flags))
+    got, rect, grid, n = _sparse_composite_single_gpu(bunny_scene, gpu_ctx, cam, w, h, nranks, tile, flags=flags)
+    common.assert_frames_equal(got, full, "sparse composite")
+    # the dealt grid covers every hit pixel and is much smaller than the frame
+    ys, xs = np.nonzero(full[2] != 0xFFFFFFFF)
+    assert rect[0] <= xs.min() and xs.max() < rect[2] and rect[1] <= ys.min() and ys.max() < rect[3]
+    assert grid[2] * grid[3] * tile * tile < 0.2 * w * h
+    assert n == -(-grid[2] * grid[3] // nranks) * tile * tile
+
+
+def test_sparse_composite_with_jitter_and_occlusion(bunny_scene, gpu_ctx):
+    w, h = 640, 360
+    cam = R.camera_reference(w, h)
+    for kw in (dict(spp=4, seed=7), dict(ao_rays=16, seed=3)):
+        flags = R.LAMBERT | R.INVERT
+        full = bunny_scene.render(cam, R.make_params(w, h, flags=flags, **kw))
+        got, _, _, _ = _sparse_composite_single_gpu(bunny_scene, gpu_ctx, cam, w, h, 3, 32, flags=flags, **kw)
+        common.assert_frames_equal(got, full, "sparse composite %r" % (kw,))
+
+
+def test_sparse_composite_with_nothing_on_screen(bunny_scene, gpu_ctx):
+    """Scene behind the camera: no tile is dealt out, rank 0 clears the whole frame, nothing is gathered."""
+    w, h = 256, 192
+    cam = R.camera_reference(w, h)
+    cam.view[14] = 5.0  # move the scene behind the eye
+    full = bunny_scene.render(cam, R.make_params(w, h))
+    assert (full[2] == 0xFFFFFFFF).all()
+    got, rect, grid, n = _sparse_composite_single_gpu(bunny_scene, gpu_ctx, cam, w, h, 4, 64)
+    assert n == 0 and grid[2] * grid[3] == 0
+    common.assert_frames_equal(got, full, "empty sparse composite")
+
+
 def test_device_outputs_on_torch_stream(bunny_scene, bunny_path):
     """Device-pointer outputs on the caller's stream (the path bench.py times)."""
     import torch
