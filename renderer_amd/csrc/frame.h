@@ -36,11 +36,13 @@ struct FrameK {
 
 // Ambient-occlusion pass: hit pixels are queued by the primary kernel and finished by k_ao.
 // A queue record is three float4: (origin.xyz, r) (normal.xyz, g) (b, pixel, out index low, out index high).
+// The occlusion kernel counts occluded rays per record in `acc`; a last small kernel turns the counts into colours.
 struct AoK {
     uint32_t rays;   // 0 = off
     float tmax;
     float* queue;    // 12 floats per record
     uint32_t* count; // records queued (zeroed before the primary kernel)
+    uint32_t* acc;   // per record: rays occluded (zeroed by the lane that queues the record)
 };
 
 struct Outputs {

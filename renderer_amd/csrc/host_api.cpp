@@ -448,18 +448,19 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
         if (out->depth) dev.depth = (float*)scene->stage[1];
         if (out->primid) dev.primid = (uint32_t*)scene->stage[2];
     }
-    AoK ao = {0, 0.0f, nullptr, nullptr};
+    AoK ao = {0, 0.0f, nullptr, nullptr, nullptr};
     if (params->ao_rays) {
-        if (f.npix > scene->ao_cap) { // queue: one 48-byte record per pixel at most, plus the counter
-            dfree(scene->ao_queue);
+        if (f.npix > scene->ao_cap) { // 256-byte header (counters), then at most one 48-byte record and one
+            dfree(scene->ao_queue);   // 4-byte accumulator per pixel
             scene->ao_cap = 0;
-            HIP_TRY(hipMalloc((void**)&scene->ao_queue, f.npix * 48 + 256));
+            HIP_TRY(hipMalloc((void**)&scene->ao_queue, f.npix * 52 + 256));
             scene->ao_cap = f.npix;
         }
         ao.rays = params->ao_rays;
         ao.tmax = params->ao_tmax > 0.0f ? params->ao_tmax : scene->vertex_diag;
         ao.count = (uint32_t*)scene->ao_queue;
         ao.queue = scene->ao_queue + 64; // records start 256 bytes in
+        ao.acc = (uint32_t*)(ao.queue + (size_t)scene->ao_cap * 12);
         HIP_TRY(hipMemsetAsync(ao.count, 0, 256, ctx->stream));
     }
     // The tile kernel keeps an 8x8 tile's candidate triangles in LDS; where triangles are much smaller than a

@@ -272,7 +272,9 @@ __device__ __forceinline__ void ao_push(const AoK& ao, bool push, const float o[
     if ((int)lane == leader) base = atomicAdd(ao.count, (uint32_t)__popcll(mask));
     base = __shfl(base, leader, 64);
     if (push) {
-        float4* q = (float4*)ao.queue + 3 * (size_t)(base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)));
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        ao.acc[slot] = 0u;
+        float4* q = (float4*)ao.queue + 3 * (size_t)slot;
         q[0] = make_float4(o[0], o[1], o[2], r);
         q[1] = make_float4(n[0], n[1], n[2], g);
         q[2] = make_float4(b, __uint_as_float(pix), __uint_as_float((uint32_t)out_index),

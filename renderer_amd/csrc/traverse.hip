@@ -35,6 +35,7 @@ namespace {
 // timing-only switches in the high flag bits (images are wrong when set; used by tools/phase_timing.py)
 constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDebugSkipAll = 1u << 22, kDebugCounts = 1u << 23;
 
+constexpr unsigned long long kAoChunk = 64; // occlusion rays per chunk; chunks are dealt round-robin to the waves
 constexpr int kStack = 40;        // per-lane stack entries; deeper trees use the brute-force kernel
 constexpr int kFrontierCap = 256;  // nodes per breadth-first level kept in LDS
 constexpr int kRangeCap = 256;     // leaf ranges per tile
@@ -100,14 +101,31 @@ __device__ __forceinline__ BlockMap map_block16(const FrameK& f, uint32_t b, uin
     return m;
 }
 
-__device__ __forceinline__ bool slab(const Ray& r, float ix, float iy, float iz, float lx, float ly, float lz, float hx,
-                                     float hy, float hz, float grow, float tmax, float& tnear) {
-    float ax = ((lx - grow) - r.ox) * ix, bx = ((hx + grow) - r.ox) * ix;
-    float ay = ((ly - grow) - r.oy) * iy, by = ((hy + grow) - r.oy) * iy;
-    float az = ((lz - grow) - r.oz) * iz, bz = ((hz + grow) - r.oz) * iz;
-    // fminf/fmaxf drop NaNs (0 * inf), which keeps the test conservative
-    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+// Ray against a box grown by `grow`, with the ray's terms folded once per ray:
+// (l - grow - o) * i = l * i - (o + grow) * i, one fused multiply-add per plane.  Box tests only have to be conservative (the hit-point guard decides which triangles
+// count), and the fold's rounding, about 2^-24 * |o * i|, is far inside the grow * |i| margin.
+struct RaySlabs {
+    float ix, iy, iz;    // 1 / direction
+    float clx, cly, clz; // (origin + grow) / direction
+    float chx, chy, chz; // (origin - grow) / direction
+};
+
+__device__ __forceinline__ RaySlabs make_slabs(float ox, float oy, float oz, float dx, float dy, float dz, float grow) {
+    RaySlabs s;
+    s.ix = 1.0f / dx, s.iy = 1.0f / dy, s.iz = 1.0f / dz;
+    s.clx = (ox + grow) * s.ix, s.cly = (oy + grow) * s.iy, s.clz = (oz + grow) * s.iz;
+    s.chx = (ox - grow) * s.ix, s.chy = (oy - grow) * s.iy, s.chz = (oz - grow) * s.iz;
+    return s;
+}
+
+__device__ __forceinline__ bool slab_folded(const RaySlabs& s, float lx, float ly, float lz, float hx, float hy,
+                                            float hz, float tmax, float& tnear) {
+    const float ax = __builtin_fmaf(lx, s.ix, -s.clx), bx = __builtin_fmaf(hx, s.ix, -s.chx);
+    const float ay = __builtin_fmaf(ly, s.iy, -s.cly), by = __builtin_fmaf(hy, s.iy, -s.chy);
+    const float az = __builtin_fmaf(lz, s.iz, -s.clz), bz = __builtin_fmaf(hz, s.iz, -s.chz);
+    // fminf/fmaxf drop NaNs (0 * inf, inf - inf), which keeps the test conservative
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     tnear = t0;
     return t0 * 0.9999f <= t1 * 1.0001f;
 }
@@ -116,8 +134,7 @@ __device__ __forceinline__ void trace(const FrameK& f, const Ray& r, const float
                                       const float4* __restrict__ TB, const float4* __restrict__ TC,
                                       const float4* __restrict__ nodes, uint32_t* stack /* column of this lane */,
                                       uint32_t stride /* lanes sharing the stack array */, Hit& best) {
-    const float ix = 1.0f / r.dx, iy = 1.0f / r.dy, iz = 1.0f / r.dz;
-    const float grow = 2.0f * f.pad;
+    const RaySlabs rs = make_slabs(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, 2.0f * f.pad);
     int sp = 0;
     uint32_t node = 0;
     for (;;) {
@@ -126,8 +143,8 @@ __device__ __forceinline__ void trace(const FrameK& f, const Ray& r, const float
         const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
         const float tmax = best.t * 1.0001f; // INFINITY until something is hit
         float tn0, tn1;
-        bool h0 = slab(r, ix, iy, iz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, grow, tmax, tn0);
-        bool h1 = slab(r, ix, iy, iz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, grow, tmax, tn1);
+        bool h0 = slab_folded(rs, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, tn0);
+        bool h1 = slab_folded(rs, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, tn1);
         if (h0 && (c0 & 0x80000000u)) {
             const uint32_t k = c0 & 0x7FFFFFFFu;
             mt_test(f, r, TA[k], TB[k], TC[k], k, best);
@@ -270,8 +287,6 @@ struct TileLds {
     float win_t[64];             // and its ray parameter
     uint32_t groups[kCutCap / kCutGroup]; // cut groups whose box meets the tile's frustum
     uint32_t n_groups;
-    Frustum fr;                  // the tile's four side planes, computed once by the first wave
-    float corner[4][4];          // directions through the grown tile's corners (facing test)
     uint32_t n_front[2];
     uint32_t n_ranges;
     uint32_t n_rec;
@@ -300,18 +315,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const float grow = 2.0f * f.pad;
     if (f.flags & kDebugSkipAll) return;
-    if (wave == 0) { // tile constants once per workgroup instead of once per wave
-        const Frustum f0 = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u));
-        if (lane < 4) {
-            S.fr.p[lane] = f0.p[lane];
-            const float m = 0.0625f;
-            float dx, dy, dz;
-            dir_at(f, (lane & 1u) ? (float)(tx0 + 8u) + m : (float)tx0 - m, (lane & 2u) ? (float)(ty0 + 8u) + m : (float)ty0 - m,
-                   dx, dy, dz);
-            S.corner[lane][0] = dx, S.corner[lane][1] = dy, S.corner[lane][2] = dz;
-            S.corner[lane][3] = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-        }
-    }
+    const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u));
     const bool stamps = (f.flags & kDebugCounts) && !(f.flags & kDebugSkipAfter2); // diagnostic build of the image
     unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
     if (stamps) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -322,7 +326,6 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     const float srgb_entry = kSrgbT[tid & 255u]; // stored to LDS later: the load stays in flight behind the first steps
     if (tid < 64) S.best[tid] = kMissKey;
     __syncthreads();
-    const Frustum fr = S.fr;
     const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
         const uint32_t g = base + tid;
@@ -432,9 +435,12 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     if (!S.overflow) {
         // directions through the four corners of the grown tile (for the facing test)
         float cdx[4], cdy[4], cdz[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) cdx[c] = S.corner[c][0], cdy[c] = S.corner[c][1], cdz[c] = S.corner[c][2];
-        const float cmax = fmaxf(fmaxf(S.corner[0][3], S.corner[1][3]), fmaxf(S.corner[2][3], S.corner[3][3]));
+        const float m = 0.0625f;
+        dir_at(f, (float)tx0 - m, (float)ty0 - m, cdx[0], cdy[0], cdz[0]);
+        dir_at(f, (float)(tx0 + 8u) + m, (float)ty0 - m, cdx[1], cdy[1], cdz[1]);
+        dir_at(f, (float)tx0 - m, (float)(ty0 + 8u) + m, cdx[2], cdy[2], cdz[2]);
+        dir_at(f, (float)(tx0 + 8u) + m, (float)(ty0 + 8u) + m, cdx[3], cdy[3], cdz[3]);
+
         const uint32_t nslots = nranges * kRangeMax;
         for (uint32_t base = 0; base < nslots; base += NT) { // block-uniform trip count
             const uint32_t q = base + tid;
@@ -455,11 +461,12 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                     // combination of the corner directions: if det is clearly negative at all four corners the
                     // triangle faces away from every ray of the tile (cull BACK, src/invert.cpp:1334).
                     const float nx = C.y * B.z - C.z * B.y, ny = C.z * B.x - C.x * B.z, nz = C.x * B.y - C.y * B.x;
-                    float dmax = -INFINITY;
+                    float dmax = -INFINITY, scale = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) dmax = fmaxf(dmax, (cdx[c] * nx + cdy[c] * ny) + cdz[c] * nz);
-                    // bound on the magnitude of the terms the dot products are summed from
-                    const float scale = cmax * ((fabsf(nx) + fabsf(ny)) + fabsf(nz));
+                    for (int c = 0; c < 4; c++) {
+                        dmax = fmaxf(dmax, (cdx[c] * nx + cdy[c] * ny) + cdz[c] * nz);
+                        scale = fmaxf(scale, (fabsf(cdx[c] * nx) + fabsf(cdy[c] * ny)) + fabsf(cdz[c] * nz));
+                    }
                     keep = keep && !(dmax < -1e-4f * scale);
                 }
             }
@@ -580,8 +587,11 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
         // 16 bytes (four pixels of a row) per lane and attachment, grid-stride: 1 KiB per wave-instruction
         const uint32_t row4 = (f.rowmajor ? f.w : f.tile) >> 2; // chunks per stored row
         const uint32_t nchunks = (uint32_t)(f.npix >> 2);          // the host keeps npix near 2^31 at most, so c + stride cannot wrap
-        const uint4 c4 = make_uint4(bg, bg, bg, bg), p4 = make_uint4(~0u, ~0u, ~0u, ~0u);
-        const float4 d4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        // The clear values stream past the caches (non-temporal stores) so the scene stays L2-resident between frames.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 c4 = {bg, bg, bg, bg}, p4 = {~0u, ~0u, ~0u, ~0u};
+        const f32x4 d4 = {1.0f, 1.0f, 1.0f, 1.0f};
         const uint32_t stride = fill_blocks * NT;
         for (uint32_t c = (blockIdx.x - ntiles) * NT + threadIdx.x; c < nchunks; c += stride) {
             uint32_t px, py;
@@ -600,9 +610,9 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
                 if (px >= f.w || py >= f.h) continue;
             }
             if (px >= hx0 && px < hx1 && py >= hy0 && py < hy1) continue; // traced by the first part of the grid
-            if (out.depth) ((float4*)out.depth)[c] = d4;
-            if (out.primid) ((uint4*)out.primid)[c] = p4;
-            if (out.color) ((uint4*)out.color)[c] = c4;
+            if (out.depth) __builtin_nontemporal_store(d4, (f32x4*)out.depth + c);
+            if (out.primid) __builtin_nontemporal_store(p4, (u32x4*)out.primid + c);
+            if (out.color) __builtin_nontemporal_store(c4, (u32x4*)out.color + c);
         }
         return;
     }
@@ -621,56 +631,13 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
 }
 
 // ------------------------------------------------------------------------------------------------
-// occlusion pass: one wave per queued hit pixel, one lane per occlusion ray
+// occlusion pass over the pixels the primary kernel queued
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool any_hit_bvh(const FrameK& f, float ox, float oy, float oz, float wx, float wy,
-                                            float wz, float tmax, const float4* __restrict__ TA,
-                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
-                                            const float4* __restrict__ nodes, uint32_t* stack, uint32_t stride) {
-    Ray r;
-    r.ox = ox, r.oy = oy, r.oz = oz, r.dx = wx, r.dy = wy, r.dz = wz;
-    const float ix = 1.0f / wx, iy = 1.0f / wy, iz = 1.0f / wz;
-    const float grow = 2.0f * f.pad, tlim = tmax * 1.0001f;
-    int sp = 0;
-    uint32_t node = 0;
-    for (;;) {
-        const float4 q0 = nodes[4 * (size_t)node + 0], q1 = nodes[4 * (size_t)node + 1];
-        const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
-        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-        float tn;
-        bool h0 = slab(r, ix, iy, iz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, grow, tlim, tn);
-        bool h1 = slab(r, ix, iy, iz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, grow, tlim, tn);
-        if (h0 && (c0 & 0x80000000u)) {
-            const uint32_t k = c0 & 0x7FFFFFFFu;
-            if (mt_any(f, ox, oy, oz, wx, wy, wz, tmax, TA[k], TB[k], TC[k])) return true;
-            h0 = false;
-        }
-        if (h1 && (c1 & 0x80000000u)) {
-            const uint32_t k = c1 & 0x7FFFFFFFu;
-            if (mt_any(f, ox, oy, oz, wx, wy, wz, tmax, TA[k], TB[k], TC[k])) return true;
-            h1 = false;
-        }
-        if (h0 && h1) {
-            stack[(size_t)sp * stride] = c1;
-            sp++;
-            node = c0;
-        } else if (h0) {
-            node = c0;
-        } else if (h1) {
-            node = c1;
-        } else {
-            if (sp == 0) return false;
-            sp--;
-            node = stack[(size_t)sp * stride];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __restrict__ TA,
-                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
-                                            const float4* __restrict__ nodes, uint32_t ntri, int use_bvh,
-                                            Outputs out) {
-    __shared__ uint32_t s_stack[kStack * 256];
+// Scenes without an LBVH (fewer than two triangles, or a tree deeper than the stack): one wave per queued pixel,
+// one lane per ray, every triangle tested.
+__global__ __launch_bounds__(256) void k_ao_brute(FrameK f, AoK ao, const float4* __restrict__ TA,
+                                                  const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                                  uint32_t ntri, Outputs out) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
     const uint32_t count = *ao.count;
@@ -688,13 +655,8 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
             if (k < ao.rays) {
                 float w[3];
                 ao_direction(n, hp, k, ao.rays, w);
-                if (use_bvh) {
-                    hit = any_hit_bvh(f, q0.x, q0.y, q0.z, w[0], w[1], w[2], ao.tmax, TA, TB, TC, nodes,
-                                      s_stack + threadIdx.x, 256);
-                } else {
-                    for (uint32_t t = 0; t < ntri && !hit; t++)
-                        hit = mt_any(f, q0.x, q0.y, q0.z, w[0], w[1], w[2], ao.tmax, TA[t], TB[t], TC[t]);
-                }
+                for (uint32_t t = 0; t < ntri && !hit; t++)
+                    hit = mt_any(f, q0.x, q0.y, q0.z, w[0], w[1], w[2], ao.tmax, TA[t], TB[t], TC[t]);
             }
             occ += (uint32_t)__popcll(__ballot(hit));
         }
@@ -702,6 +664,120 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
             const float a = 1.0f - (float)occ / (float)ao.rays;
             ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, q0.w * a, q1.w * a, q2.x * a);
         }
+    }
+}
+
+// LBVH scenes: a stream of rays.  A lane whose ray has ended (the first occluder ends it) takes the next ray of
+// the wave's share as soon as a quarter of the wave is idle, so short rays do not wait for the wave's longest
+// traversal.  Each step the wave does what most of its live lanes are waiting for: either one node (two child
+// boxes) or one leaf (one triangle).  The set of leaves a ray reaches does not depend on the visiting order, and
+// the per-pixel result is a sum of hits, so the image does not depend on the scheduling.
+__global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __restrict__ TA,
+                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                            const float4* __restrict__ nodes, Outputs out) {
+    extern __shared__ uint32_t s_stack[]; // one column per lane, (tree height + 1) entries
+    uint32_t* const stack = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t total = (uint64_t)(*ao.count) * ao.rays;
+    const bool narrow = total < 0xFFFFFFFFull; // ray index -> (record, ray) without a 64-bit division
+    const float4* queue = (const float4*)ao.queue;
+    const float grow = 2.0f * f.pad, tlim = ao.tmax * 1.0001f;
+    const uint32_t hseed = hash32(f.seed ^ 0xA0761D65u);
+    bool active = false, more = total != 0;
+    uint64_t cur = 0, end = 0; // the wave's current chunk of ray indices (wave-uniform)
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4u;
+    uint64_t chunk = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); // next chunk this wave takes
+    uint32_t rec = 0, node = 0, sp = 0;
+    float ox = 0, oy = 0, oz = 0, wx = 0, wy = 0, wz = 0;
+    RaySlabs rs = {};
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (more && __popcll(idle) >= 16) {
+            if (cur == end) { // next chunk of this wave: chunks are dealt round-robin over the grid's waves
+                const uint64_t base = chunk * kAoChunk;
+                chunk += nwaves;
+                cur = base < total ? base : total;
+                end = base + kAoChunk < total ? base + kAoChunk : total;
+            }
+            const uint64_t g = cur + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            cur = cur + (uint32_t)__popcll(idle) < end ? cur + (uint32_t)__popcll(idle) : end;
+            if (cur == end && chunk * kAoChunk >= total) more = false;
+            if (!active) {
+                if (g < end) {
+                    uint32_t k;
+                    if (narrow)
+                        rec = (uint32_t)g / ao.rays, k = (uint32_t)g % ao.rays;
+                    else
+                        rec = (uint32_t)(g / ao.rays), k = (uint32_t)(g % ao.rays);
+                    const float4 q0 = queue[3 * (size_t)rec], q1 = queue[3 * (size_t)rec + 1];
+                    const uint32_t pix = __float_as_uint(queue[3 * (size_t)rec + 2].y);
+                    const float nrm[3] = {q1.x, q1.y, q1.z};
+                    float w[3];
+                    ao_direction(nrm, hash32(pix ^ hseed), k, ao.rays, w);
+                    ox = q0.x, oy = q0.y, oz = q0.z;
+                    wx = w[0], wy = w[1], wz = w[2];
+                    rs = make_slabs(ox, oy, oz, wx, wy, wz, grow);
+                    node = 0, sp = 0;
+                    active = true;
+                }
+            }
+        }
+        const uint64_t live = __ballot(active);
+        if (!live) {
+            if (!more) break;
+            continue;
+        }
+        const bool at_leaf = active && (node & 0x80000000u);
+        const bool leaf_step = 2 * __popcll(__ballot(at_leaf)) > __popcll(live);
+        bool ended = false, hit = false;
+        if (leaf_step) {
+            if (at_leaf) {
+                const uint32_t k = node & 0x7FFFFFFFu;
+                if (mt_any(f, ox, oy, oz, wx, wy, wz, ao.tmax, TA[k], TB[k], TC[k]))
+                    hit = true, ended = true;
+                else if (sp == 0)
+                    ended = true;
+                else
+                    node = stack[(size_t)(--sp) * 256];
+            }
+        } else if (active && !at_leaf) {
+            const float4 q0 = nodes[4 * (size_t)node + 0], q1 = nodes[4 * (size_t)node + 1];
+            const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
+            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            float tn;
+            const bool h0 = slab_folded(rs, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlim, tn);
+            const bool h1 = slab_folded(rs, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlim, tn);
+            if (h0 && h1) {
+                stack[(size_t)sp * 256] = c1;
+                sp++;
+                node = c0;
+            } else if (h0) {
+                node = c0;
+            } else if (h1) {
+                node = c1;
+            } else if (sp == 0) {
+                ended = true;
+            } else {
+                node = stack[(size_t)(--sp) * 256];
+            }
+        }
+        if (ended) {
+            // the result is not read back here, so the wave does not wait for the atomic
+            if (hit) __hip_atomic_fetch_add(&ao.acc[rec], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            active = false;
+        }
+    }
+}
+
+// After the ray stream: one lane per queued pixel turns its occlusion count into the stored colour.
+__global__ __launch_bounds__(256) void k_ao_resolve(FrameK f, AoK ao, Outputs out) {
+    const uint32_t count = *ao.count;
+    const float4* queue = (const float4*)ao.queue;
+    for (uint32_t rec = blockIdx.x * 256u + threadIdx.x; rec < count; rec += gridDim.x * 256u) {
+        const float4 q0 = queue[3 * (size_t)rec], q1 = queue[3 * (size_t)rec + 1], q2 = queue[3 * (size_t)rec + 2];
+        const uint64_t oi = (uint64_t)__float_as_uint(q2.z) | ((uint64_t)__float_as_uint(q2.w) << 32);
+        const float a = 1.0f - (float)ao.acc[rec] / (float)ao.rays;
+        ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, q0.w * a, q1.w * a, q2.x * a);
     }
 }
 
@@ -772,10 +848,19 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
 namespace inv {
 hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out) {
     if (!ao.rays || f.npix == 0) return hipSuccess;
-    const int use_bvh = sc.has_bvh && sc.height <= (uint32_t)kStack;
-    // a fixed grid walks the queue (its length is only known on the device): 4 waves per block, 4 blocks per CU
-    hipLaunchKernelGGL(k_ao, dim3(1024), dim3(256), 0, s, f, ao, (const float4*)sc.triA, (const float4*)sc.triB,
-                       (const float4*)sc.triC, (const float4*)sc.nodes, sc.ntri, use_bvh, out);
+    // fixed grids walk the queue (its length is only known on the device)
+    if (!sc.has_bvh || sc.height > (uint32_t)kStack) {
+        hipLaunchKernelGGL(k_ao_brute, dim3(1024), dim3(256), 0, s, f, ao, (const float4*)sc.triA,
+                           (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, out);
+        return hipGetLastError();
+    }
+    const uint32_t entries = std::min<uint32_t>(sc.height + 1u, (uint32_t)kStack + 1u);
+    const size_t lds = (size_t)entries * 256u * sizeof(uint32_t);
+    // as many workgroups as stay resident at once: 256 CUs x what the stack's LDS share allows (at most 8)
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / (lds + 512u)));
+    hipLaunchKernelGGL(k_ao, dim3(256u * per_cu), dim3(256), lds, s, f, ao, (const float4*)sc.triA,
+                       (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, out);
+    if (out.color) hipLaunchKernelGGL(k_ao_resolve, dim3(512), dim3(256), 0, s, f, ao, out);
     return hipGetLastError();
 }
 } // namespace inv

@@ -75,7 +75,8 @@ class SparseComposite:
         if rank == 0:
             self.frame = torch.empty(3, width * height, dtype=torch.int32, device=device)
             self.gathered = torch.empty(world, 3, self.slot_elems, dtype=torch.int32, device=device)
-            self.planes = self.gathered[0]  # rank 0's own (unused) part of the gather
+            # rank 0's own part of the gather is never read; it only has to exist and not alias the output
+            self.planes = torch.zeros(3, self.slot_elems, dtype=torch.int32, device=device)
             self._out = self.frame
         else:
             self.planes = torch.empty(3, self.slot_elems, dtype=torch.int32, device=device)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# One pass of every measurement kept under profiles/: bench lines, rocprofv3 kernel stats, the two HBM counter
+# passes, phase timing, per-tile statistics and the instruction-mix table.  Run on the GPU box from the repo root:
+#     bash tools/profile_round.sh TAG
+set -e
+TAG=${1:-r01}
+R=$(pwd)
+O=$R/gpurun_out/$TAG
+rm -rf "$O" && mkdir -p "$O"
+export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline --steps 200 --warmup 20"
+timeout -k 10 200 python3 bench.py > "$O/bench_default.json"
+timeout -k 10 200 python3 bench.py --workload bunny_4k_16spp > "$O/bench_4k_16spp.json"
+timeout -k 10 200 python3 bench.py --workload bunny_1080p_ao64 > "$O/bench_ao64.json"
+(cd /tmp && timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $B > /dev/null 2>&1)
+(cd /tmp && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- $B > /dev/null 2>&1)
+(cd /tmp && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- $B > /dev/null 2>&1)
+(cd /tmp && timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_ao" -- $B --workload bunny_1080p_ao64 > /dev/null 2>&1)
+timeout -k 10 120 python3 tools/phase_timing.py > "$O/phase_timing.txt" 2>&1
+timeout -k 10 120 python3 tools/tile_stats.py > "$O/tile_stats.txt" 2>&1
+bash tools/pmc_phases.sh > /dev/null 2>&1 && cp gpurun_out/pmc_phases.txt "$O/pmc_phases.txt"
+timeout -k 10 300 python3 tools/config4.py > "$O/config4.txt" 2>&1
+echo done

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 import objfmt  # noqa: E402
 import renderer_amd as R  # noqa: E402
@@ -25,7 +26,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     a = ap.parse_args()
     w, h = a.width, a.height
-    ctx = R.Context(0)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = R.Context(0, stream=stream.cuda_stream)
     scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))
     cam = R.camera_reference(w, h)
     _, d, p = scene.render(cam, R.make_params(w, h, flags=SKIP_AFTER2 | COUNTS))
@@ -34,9 +37,14 @@ def main():
     print("tiles traced %d; ranges mean %.1f max %d; records mean %.1f max %d" %
           (m.sum(), nr[m].mean(), nr[m].max(), nrec[m].mean(), nrec[m].max()))
     print("records histogram [0,1,8,16,32,64,128,256):", np.histogram(nrec[m], bins=[0, 1, 8, 16, 32, 64, 128, 256])[0])
-    for _ in range(3):
-        _, d, _ = scene.render(cam, R.make_params(w, h, flags=R.LAMBERT | R.INVERT | COUNTS))
-    d = d.view(np.uint32)
+    # stamps of the last of several launches enqueued back to back, as in a stream of frames (a launch on an idle
+    # device starts its workgroups over a few microseconds, XCD after XCD)
+    buf = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
+    prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT | COUNTS)
+    for _ in range(8):
+        scene.render_device(cam, prm, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr())
+    stream.synchronize()
+    d = buf[1].cpu().numpy().view(np.uint32).reshape(h, w)
     ys, xs = np.nonzero(m)
     t1, t2, t3, n = (d[::8, k::8][ys, xs].astype(np.int64) for k in range(4))
     for name, t in (("phase 1", t1), ("phase 2", t2), ("phase 3", t3), ("total", t1 + t2 + t3)):
@@ -49,7 +57,6 @@ def main():
     print("tile start spread: %.2f us; last tile end - first tile start: %.2f us" %
           ((start.max() - start.min()) / 100.0, ((start + real).max() - start.min()) / 100.0))
     rel = (start - start.min()) / 100.0
-    print("start (us) by block index decile:", " ".join("%.2f" % rel[int(q * (len(rel) - 1) / 10)] for q in range(11)))
     print("start (us) percentiles 0..100:   ", " ".join("%.2f" % v for v in np.percentile(rel, range(0, 101, 10))))
     end = rel + real / 100.0
     print("end   (us) percentiles 0..100:   ", " ".join("%.2f" % v for v in np.percentile(end, range(0, 101, 10))))
