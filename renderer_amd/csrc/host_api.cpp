@@ -1,6 +1,7 @@
 // C ABI (include/invert.h): handles, argument checks, error strings and the host side of the draw.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -462,12 +463,6 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
         ao.queue = scene->ao_queue + 64; // records start 256 bytes in
         ao.acc = (uint32_t*)(ao.queue + (size_t)scene->ao_cap * 12);
         HIP_TRY(hipMemsetAsync(ao.count, 0, 256, ctx->stream));
-    }
-    // The tile kernel keeps an 8x8 tile's candidate triangles in LDS; where triangles are much smaller than a
-    // pixel those lists overflow, so such frames go straight to the per-lane traversal.
-    if (scene->d.has_bvh && !(f.flags & (INV_BRUTE_FORCE | INV_LANE_TRAVERSAL))) {
-        const double rect_px = (double)(f.rx1 - f.rx0) * (double)(f.ry1 - f.ry0);
-        if (rect_px > 0.0 && (double)scene->d.ntri * 64.0 / rect_px > 96.0) f.flags |= INV_LANE_TRAVERSAL;
     }
     const bool brute = (params->flags & INV_BRUTE_FORCE) || !scene->d.has_bvh;
     if (brute)

@@ -39,7 +39,7 @@ constexpr unsigned long long kAoChunk = 64; // occlusion rays per chunk; chunks 
 constexpr int kStack = 40;        // per-lane stack entries; deeper trees use the brute-force kernel
 constexpr int kFrontierCap = 256;  // nodes per breadth-first level kept in LDS
 constexpr int kRangeCap = 256;     // leaf ranges per tile
-constexpr int kTileCap = 192;      // candidate triangle records per tile (at most 64 per wave: one mask bit each)
+constexpr int kTileCap = 256;      // candidate triangle records per tile (at most 64 per wave: one mask bit each)
 
 struct BlockMap {
     uint32_t px, py;
@@ -290,7 +290,9 @@ struct TileLds {
     uint32_t n_front[2];
     uint32_t n_ranges;
     uint32_t n_rec;
-    uint32_t overflow;
+    uint32_t overflow;     // more subtrees or leaf ranges than the lists hold: per-lane traversal instead
+    uint32_t rec_overflow; // more candidate records than the list holds: phase 3 runs in batches
+    uint32_t rec_k[kTileCap]; // position of each record in the sorted triangle arrays
 };
 
 // Append `flag` lanes' values to an LDS list: one counter update per wave, lanes ranked by ballot.
@@ -305,7 +307,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool flag, ui
 }
 
 // The trace part of the grid: one workgroup of NW waves per 8x8 pixel tile of the rectangle that can contain hits.
-template <int NW>
+template <int NW, bool BATCHED>
 __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint32_t tx0, uint32_t ty0,
                                            const float4* __restrict__ TA, const float4* __restrict__ TB,
                                            const float4* __restrict__ TC, const float4* __restrict__ nodes,
@@ -322,7 +324,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
 
     // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
     //      is still a subtree after that is opened breadth-first ----
-    if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
+    if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.rec_overflow = 0, S.n_groups = 0;
     const float srgb_entry = kSrgbT[tid & 255u]; // stored to LDS later: the load stays in flight behind the first steps
     if (tid < 64) S.best[tid] = kMissKey;
     __syncthreads();
@@ -432,7 +434,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     if (tid < 256) S.srgb[tid] = srgb_entry;
     // ---- phase 2: one candidate triangle per lane against the tile's frustum and facing ----
     const uint32_t nranges = S.n_ranges;
-    if (!S.overflow) {
+    // the triangles of ranges [r0, r1) that can cover a sample of the tile -> S.u.t.rec (arguments block-uniform)
+    const auto build_records = [&](uint32_t r0, uint32_t r1) {
         // directions through the four corners of the grown tile (for the facing test)
         float cdx[4], cdy[4], cdz[4];
         const float m = 0.0625f;
@@ -440,17 +443,17 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
         dir_at(f, (float)(tx0 + 8u) + m, (float)ty0 - m, cdx[1], cdy[1], cdz[1]);
         dir_at(f, (float)tx0 - m, (float)(ty0 + 8u) + m, cdx[2], cdy[2], cdz[2]);
         dir_at(f, (float)(tx0 + 8u) + m, (float)(ty0 + 8u) + m, cdx[3], cdy[3], cdz[3]);
-
-        const uint32_t nslots = nranges * kRangeMax;
+        const uint32_t nslots = (r1 - r0) * kRangeMax;
         for (uint32_t base = 0; base < nslots; base += NT) { // block-uniform trip count
             const uint32_t q = base + tid;
             bool keep = false;
+            uint32_t k = 0;
             float4 A, B, C;
             if (q < nslots) {
-                const uint2 rg = S.u.t.ranges[q / kRangeMax];
+                const uint2 rg = S.u.t.ranges[r0 + q / kRangeMax];
                 const uint32_t off = q % kRangeMax;
                 if (off < rg.y) {
-                    const uint32_t k = rg.x + off;
+                    k = rg.x + off;
                     A = TA[k], B = TB[k], C = TC[k];
                     const float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
                     const float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
@@ -476,15 +479,17 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                     S.u.t.rec[at][0] = A;
                     S.u.t.rec[at][1] = B;
                     S.u.t.rec[at][2] = C;
+                    if (BATCHED) S.rec_k[at] = k;
                 } else {
-                    S.overflow = 1;
+                    S.rec_overflow = 1;
                 }
             }
         }
-    }
+    };
+    if (!BATCHED && !S.overflow) build_records(0, nranges);
     __syncthreads();
 
-    if (S.overflow) { // more candidates than the LDS lists hold: the first wave traverses per lane
+    if (S.overflow || (!BATCHED && S.rec_overflow)) { // more than the LDS lists hold: the first wave traverses per lane
         if (wave == 0 && valid) pixel_by_traversal(f, px, py, oi, TA, TB, TC, nodes, S.u.stack + lane, 64, ao, out);
         return;
     }
@@ -498,8 +503,14 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     }
     if (stamps) t2 = __builtin_amdgcn_s_memtime();
     // ---- phase 3: every wave tests its share of the records for all 64 pixels; an LDS min per pixel picks the
-    //      winning key; the lane that holds it hands its barycentric terms to the first wave, which shades ----
-    const uint32_t nrec = S.n_rec;
+    //      winning key; the lane that holds it hands its barycentric terms to the first wave, which shades.
+    //      The BATCHED variant (scenes whose triangles are much smaller than a pixel: more candidates per tile
+    //      than the record list holds) works through the ranges in batches that always fit, rebuilding the
+    //      records for every batch; the winner is then named by its position in the sorted triangle arrays
+    //      instead of its LDS slot. ----
+    constexpr bool batched = BATCHED;
+    constexpr uint32_t kBatchRanges = kTileCap / kRangeMax;
+    const uint32_t nbatches = batched ? (nranges + kBatchRanges - 1u) / kBatchRanges : 1u;
     const uint32_t pix = py * f.w + px;
     float sr = 0.0f, sg = 0.0f, sb = 0.0f; // first wave only
     Hit first = miss_hit();
@@ -509,16 +520,26 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
         sample_offset(pix, s, f.seed, sx, sy);
         const Ray ray = make_ray(f, px, py, sx, sy);
         Hit best = miss_hit();
-        // cheap pass: which of this wave's records contain the sample (one bit per record, no divergence) ...
-        uint64_t inside = 0;
-        for (uint32_t j = wave, i = 0; j < nrec; j += NW, i++)
-            inside |= (uint64_t)mt_inside(ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2]) << i;
-        // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
-        while (inside) {
-            const uint32_t i = (uint32_t)__ffsll((long long)inside) - 1u;
-            inside &= inside - 1ull;
-            const uint32_t j = wave + i * NW;
-            mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], j, best);
+        for (uint32_t bt = 0; bt < nbatches; bt++) { // block-uniform
+            if (batched) {
+                __syncthreads(); // every wave is done with the previous records
+                if (tid == 0) S.n_rec = 0;
+                __syncthreads();
+                build_records(bt * kBatchRanges, min((bt + 1u) * kBatchRanges, nranges));
+                __syncthreads();
+            }
+            const uint32_t nrec = min(S.n_rec, (uint32_t)kTileCap);
+            // cheap pass: which of this wave's records contain the sample (one bit per record, no divergence) ...
+            uint64_t inside = 0;
+            for (uint32_t j = wave, i = 0; j < nrec; j += NW, i++)
+                inside |= (uint64_t)mt_inside(ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2]) << i;
+            // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
+            while (inside) {
+                const uint32_t i = (uint32_t)__ffsll((long long)inside) - 1u;
+                inside &= inside - 1ull;
+                const uint32_t j = wave + i * NW;
+                mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], batched ? S.rec_k[j] : j, best);
+            }
         }
         if (best.key != kMissKey) atomicMin(&S.best[lane], (unsigned long long)best.key);
         __syncthreads();
@@ -533,7 +554,10 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                 const float4 wv = S.win[lane];
                 Hit h;
                 h.key = key, h.t = S.win_t[lane], h.un = wv.x, h.vn = wv.y, h.det = wv.z, h.slot = __float_as_uint(wv.w);
-                shade_hit(f, h, S.u.t.rec[h.slot][0], S.u.t.rec[h.slot][1], S.u.t.rec[h.slot][2], r, g, b);
+                if (batched)
+                    shade_hit(f, h, TA[h.slot], TB[h.slot], TC[h.slot], r, g, b);
+                else
+                    shade_hit(f, h, S.u.t.rec[h.slot][0], S.u.t.rec[h.slot][1], S.u.t.rec[h.slot][2], r, g, b);
                 if (s == 0) first = h;
             }
             sr = sr + r, sg = sg + g, sb = sb + b;
@@ -553,13 +577,16 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     }
     if (wave != 0 || !valid) return;
     const uint32_t ws = first.key != kMissKey ? first.slot : 0u;
-    finish_pixel(f, ao, out, oi, pix, ray0, first, S.u.t.rec[ws][1], S.u.t.rec[ws][2], sr, sg, sb, S.srgb);
+    if (batched)
+        finish_pixel(f, ao, out, oi, pix, ray0, first, TB[ws], TC[ws], sr, sg, sb, S.srgb);
+    else
+        finish_pixel(f, ao, out, oi, pix, ray0, first, S.u.t.rec[ws][1], S.u.t.rec[ws][2], sr, sg, sb, S.srgb);
 }
 
 // Grid = [8x8 tiles of the hit rectangle] ++ [fill blocks].  The fill blocks store the clear values of every pixel
 // whose 8x8 tile is not in the first part, grid-stride: 16 bytes per lane when the row length and the buffer
 // addresses allow it (vec4), else one pixel per lane in 32x8 pixel blocks (two 128-byte lines per wave-instruction).
-template <int NW>
+template <int NW, bool BATCHED>
 __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tiles_x, uint32_t ntiles,
                                                          uint32_t fill_blocks, uint32_t pixel_blocks, int vec4,
                                                          uint32_t row4_magic,
@@ -577,7 +604,7 @@ __global__ __launch_bounds__(NW * 64) void k_render_tile(FrameK f, uint32_t tile
             uint64_t dummy;
             if (!out_index(f, tx0, ty0, dummy)) return;
         }
-        trace_tile<NW>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+        trace_tile<NW, BATCHED>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
         return;
     }
     const uint32_t hx0 = f.rx0 & ~7u, hy0 = f.ry0 & ~7u;
@@ -822,18 +849,27 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         tiles_y = ((f.ry1 + 7u) >> 3) - (f.ry0 >> 3);
     }
     const uint32_t ntiles = tiles_x * tiles_y;
-    const int nw = tile_waves();
+    // Where triangles are much smaller than a pixel an 8x8 tile has more candidates than the record list holds:
+    // such frames take the variant that works through them in batches.
+    const double rect_px = (double)(f.rx1 - f.rx0) * (double)(f.ry1 - f.ry0);
+    const bool dense = ntiles != 0 && (double)sc.ntri * 64.0 / rect_px > 96.0;
+    const int nw = dense ? 4 : tile_waves();
     const uint32_t nt = (uint32_t)nw * 64u;
     const uint64_t fill_work = vec4 ? ((f.npix >> 2) + nt - 1u) / nt : pixel_blocks;
     const uint32_t fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
     const uint32_t row4 = std::max(1u, (f.rowmajor ? f.w : f.tile) >> 2);
     const uint32_t row4_magic = row4 == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / row4);
 #define INV_LAUNCH_TILE(NW)                                                                                          \
-    hipLaunchKernelGGL(k_render_tile<NW>, dim3(ntiles + fill_blocks), dim3(NW * 64), 0, s, f, tiles_x, ntiles,       \
+    hipLaunchKernelGGL((k_render_tile<NW, false>), dim3(ntiles + fill_blocks), dim3(NW * 64), 0, s, f, tiles_x, ntiles, \
                        fill_blocks, pixel_blocks, vec4, row4_magic, (const float4*)sc.triA, (const float4*)sc.triB, \
                        (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,                        \
                        (const float4*)sc.cut_groups, sc.ncut, ao, out)
-    if (nw == 8)
+    if (dense)
+        hipLaunchKernelGGL((k_render_tile<4, true>), dim3(ntiles + fill_blocks), dim3(256), 0, s, f, tiles_x, ntiles,
+                           fill_blocks, pixel_blocks, vec4, row4_magic, (const float4*)sc.triA, (const float4*)sc.triB,
+                           (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,
+                           (const float4*)sc.cut_groups, sc.ncut, ao, out);
+    else if (nw == 8)
         INV_LAUNCH_TILE(8);
     else if (nw == 16)
         INV_LAUNCH_TILE(16);
