@@ -280,30 +280,34 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     DeviceScene& d = s->d;
     d.nv = nv;
     d.ntri = (uint32_t)ntri64;
-    // largest |coordinate| the rays can meet (feeds the guard pad)
+    // Largest |coordinate| the rays can meet (feeds the guard pad) and the bounding box of the vertices as stored,
+    // over all instances.  Rounding is monotonic, so the extremes of fl(v + t) over vertices and instances are
+    // fl(vmin + tmin) and fl(vmax + tmax) per axis: no need to visit every pair.
     float max_abs = 0.0f;
-    for (uint32_t i = 0; i < nv; i++)
-        for (int c = 0; c < 3; c++) {
-            float v = mesh->xyzw[(size_t)i * 4 + c];
-            if (translations_xyz) {
-                for (uint32_t j = 0; j < ninst; j++) max_abs = std::fmax(max_abs, std::fabs(v + translations_xyz[(size_t)j * 3 + c]));
-            } else {
-                max_abs = std::fmax(max_abs, std::fabs(v));
+    if (nv) {
+        float vlo[3] = {INFINITY, INFINITY, INFINITY}, vhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < nv; i++)
+            for (int c = 0; c < 3; c++) {
+                const float v = mesh->xyzw[(size_t)i * 4 + c];
+                vlo[c] = std::fmin(vlo[c], v), vhi[c] = std::fmax(vhi[c], v);
             }
-        }
-    s->max_abs = max_abs;
-    if (nv) { // bounding box of the vertices as stored (all instances)
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t j = 0; j < ninst; j++)
-            for (uint32_t i = 0; i < nv; i++)
-                for (int c = 0; c < 3; c++) {
-                    float v = mesh->xyzw[(size_t)i * 4 + c];
-                    if (translations_xyz) v = v + translations_xyz[(size_t)j * 3 + c];
-                    lo[c] = std::fmin(lo[c], v), hi[c] = std::fmax(hi[c], v);
+        float lo[3], hi[3];
+        for (int c = 0; c < 3; c++) {
+            lo[c] = vlo[c], hi[c] = vhi[c];
+            if (translations_xyz) {
+                float tlo = INFINITY, thi = -INFINITY;
+                for (uint32_t j = 0; j < ninst; j++) {
+                    const float t = translations_xyz[(size_t)j * 3 + c];
+                    tlo = std::fmin(tlo, t), thi = std::fmax(thi, t);
                 }
+                lo[c] = vlo[c] + tlo, hi[c] = vhi[c] + thi;
+            }
+            max_abs = std::fmax(max_abs, std::fmax(std::fabs(lo[c]), std::fabs(hi[c])));
+        }
         const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
         s->vertex_diag = std::sqrt((ex * ex + ey * ey) + ez * ez);
     }
+    s->max_abs = max_abs;
     float* d_tr = nullptr;
     int rc = INV_OK;
     hipError_t e = hipSuccess;

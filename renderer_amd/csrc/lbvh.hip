@@ -15,6 +15,7 @@ namespace {
 constexpr int kSortThreads = 256;
 constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems; // keys per workgroup per pass
+constexpr uint32_t kMaxLevels = 200;                 // refit launches at most (a tree over 63+32-bit keys has under 100 levels)
 
 // ------------------------------------------------------------------------------------------
 // 1. triangle boxes + scene bounds (two-stage min/max reduction, no float atomics)
@@ -359,17 +360,26 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
 //    last sorted leaf under the node (written by the hierarchy kernel).  union_box[i] (8 floats)
 //    carries the node's own box and height upwards.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void arrive_at(uint32_t node, uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
-                                          uint32_t* __restrict__ next_count) {
-    if (node == 0xFFFFFFFFu) return;
-    if (atomicAdd(&arrive[node], 1u) == 1u) next[atomicAdd(next_count, 1u)] = node; // second child: ready next launch
+// Call with the whole wave converged (`live` selects the lanes that have a node).  The ready list's counter is
+// one address for the whole grid, so a wave updates it once for all of its lanes.
+__device__ __forceinline__ void arrive_at(bool live, uint32_t node, uint32_t* __restrict__ arrive,
+                                          uint32_t* __restrict__ next, uint32_t* __restrict__ next_count) {
+    const bool second = live && node != 0xFFFFFFFFu && atomicAdd(&arrive[node], 1u) == 1u; // ready next launch
+    const uint64_t mask = __ballot(second);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (second) next[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = node;
 }
 
 __global__ __launch_bounds__(256) void k_refit_leaves(uint32_t n, const uint32_t* __restrict__ leaf_parent,
                                                       uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
                                                       uint32_t* __restrict__ next_count) {
-    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf < n) arrive_at(leaf_parent[leaf], arrive, next, next_count);
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    arrive_at(leaf < n, leaf < n ? leaf_parent[leaf] : 0xFFFFFFFFu, arrive, next, next_count);
 }
 
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
@@ -386,16 +396,11 @@ __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                     const float4* __restrict__ TC, const uint32_t* __restrict__ child,
-                                                     const uint32_t* __restrict__ parent,
-                                                     const uint32_t* __restrict__ ready, uint32_t nready,
-                                                     uint32_t* __restrict__ arrive, float* __restrict__ union_box,
-                                                     float* __restrict__ nodes, uint32_t* __restrict__ next,
-                                                     uint32_t* __restrict__ next_count) {
-    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nready) return;
-    const uint32_t node = ready[q];
+// Finishes one internal node (both children are complete); returns its parent.
+__device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                               const float4* __restrict__ TC, const uint32_t* __restrict__ child,
+                                               const uint32_t* __restrict__ parent, uint32_t node,
+                                               float* __restrict__ union_box, float* __restrict__ nodes) {
     const uint32_t c0 = child[2 * (size_t)node], c1 = child[2 * (size_t)node + 1];
     float l0[3], h0[3], l1[3], h1[3];
     uint32_t ht0, ht1;
@@ -411,48 +416,124 @@ __global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ 
     float4* u = (float4*)union_box + 2 * (size_t)node;
     u[0] = make_float4(fminf(l0[0], l1[0]), fminf(l0[1], l1[1]), fminf(l0[2], l1[2]), fmaxf(h0[0], h1[0]));
     u[1] = make_float4(fmaxf(h0[1], h1[1]), fmaxf(h0[2], h1[2]), __uint_as_float(ht), 0.0f);
-    arrive_at(parent[node], arrive, next, next_count);
+    return parent[node];
 }
 
-// ------------------------------------------------------------------------------------------
-// 7. cut: a flat start set for the tile kernel.  The tree is opened breadth-first from the root
-//    until every open subtree has at most kRangeMax leaves or kCutCap records are in use.  A record
-//    is 8 floats: (lo.xyz, ref) (hi.xyz, count).  count <= kRangeMax: ref is the first sorted leaf
-//    of a range taken whole; otherwise ref is an internal node that still has to be descended.
-//    One lane does this (a few thousand dependent loads, once per scene).
-// ------------------------------------------------------------------------------------------
-__global__ void k_build_cut(const float* __restrict__ nodes, float* __restrict__ cut, float* __restrict__ groups,
-                            uint32_t* __restrict__ ncut_out,
-                            uint32_t* __restrict__ queue /* 2 * kCutCap entries: (parent << 1) | side */) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t head = 0, tail = 0, nout = 0;
-    queue[tail++] = 0u; // root, side 0
-    queue[tail++] = 1u; // root, side 1
-    while (head < tail) {
-        const uint32_t e = queue[head++ % (2 * kCutCap)];
-        const uint32_t parent = e >> 1, side = e & 1u;
-        const float* nd = nodes + 16 * (size_t)parent;
-        const uint32_t c = __float_as_uint(nd[12 + side]);
-        const uint32_t gamma = __float_as_uint(nd[12]) & 0x7FFFFFFFu;
-        const uint32_t lo = __float_as_uint(nd[14]), hi = __float_as_uint(nd[15]);
-        const uint32_t first = side ? gamma + 1u : lo;
-        const uint32_t count = side ? hi - gamma : gamma - lo + 1u;
-        const bool small = (c & 0x80000000u) || count <= kRangeMax;
-        // opening a subtree replaces one pending record by two
-        if (!small && nout + (tail - head) + 2u <= kCutCap) {
-            queue[tail++ % (2 * kCutCap)] = 2u * c;
-            queue[tail++ % (2 * kCutCap)] = 2u * c + 1u;
-            continue;
-        }
-        float* r = cut + 8 * (size_t)nout++;
-        r[0] = nd[6 * side + 0], r[1] = nd[6 * side + 1], r[2] = nd[6 * side + 2];
-        r[3] = __uint_as_float(small ? first : c);
-        r[4] = nd[6 * side + 3], r[5] = nd[6 * side + 4], r[6] = nd[6 * side + 5];
-        r[7] = __uint_as_float(count);
+__global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                     const float4* __restrict__ TC, const uint32_t* __restrict__ child,
+                                                     const uint32_t* __restrict__ parent,
+                                                     const uint32_t* __restrict__ ready,
+                                                     const uint32_t* __restrict__ ready_count,
+                                                     uint32_t* __restrict__ arrive, float* __restrict__ union_box,
+                                                     float* __restrict__ nodes, uint32_t* __restrict__ next,
+                                                     uint32_t* __restrict__ next_count) {
+    // The level's size is read on the device, so the host can queue several levels without waiting for each.
+    const uint32_t nready = *ready_count;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nready; base += gridDim.x * blockDim.x) { // wave-uniform
+        const uint32_t q = base + threadIdx.x;
+        uint32_t up = 0xFFFFFFFFu;
+        if (q < nready) up = refit_node(TA, TB, TC, child, parent, ready[q], union_box, nodes);
+        arrive_at(q < nready, up, arrive, next, next_count);
     }
-    *ncut_out = nout;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// 7. cut: a flat start set for the tile kernel.  The tree is opened breadth-first from the root,
+//    level by level, until every open subtree has at most kRangeMax leaves or kCutCap records are in
+//    use.  A record is 8 floats: (lo.xyz, ref) (hi.xyz, count).  count <= kRangeMax: ref is the first
+//    sorted leaf of a range taken whole; otherwise ref is an internal node that still has to be
+//    descended.  One workgroup: the frontier (at most kCutCap entries) lives in LDS, two entries per
+//    lane, and order-preserving block scans place the records and the next frontier, so the result
+//    does not depend on scheduling.
+// ------------------------------------------------------------------------------------------
+constexpr int kCutThreads = kCutCap / 2;
+
+// Exclusive ranks, in entry order, of two flags per lane (entry tid and entry tid + kCutThreads); returns the total.
+__device__ __forceinline__ uint32_t block_ranks(bool f0, bool f1, uint32_t (*tot)[kCutThreads / 64], uint32_t& r0,
+                                                uint32_t& r1) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
+    const uint64_t below = (1ull << lane) - 1ull;
+    __syncthreads(); // the totals of the previous scan have been read
+    if (lane == 0) tot[0][wave] = (uint32_t)__popcll(m0), tot[1][wave] = (uint32_t)__popcll(m1);
+    __syncthreads();
+    uint32_t before0 = 0, before1 = 0, all0 = 0, all1 = 0;
+    for (uint32_t w = 0; w < kCutThreads / 64; w++) {
+        const uint32_t a = tot[0][w], b = tot[1][w];
+        if (w < wave) before0 += a, before1 += b;
+        all0 += a, all1 += b;
+    }
+    r0 = before0 + (uint32_t)__popcll(m0 & below);
+    r1 = all0 + before1 + (uint32_t)__popcll(m1 & below);
+    return all0 + all1;
+}
+
+__global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restrict__ nodes, float* __restrict__ cut,
+                                                          float* __restrict__ groups, uint32_t* __restrict__ ncut_out) {
+    __shared__ uint32_t frontier[2][kCutCap]; // (parent << 1) | side
+    __shared__ uint32_t tot[2][kCutThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) frontier[0][0] = 0u, frontier[0][1] = 1u; // the root's two sides
+    uint32_t nf = 2, nout = 0; // block-uniform
+    int cur = 0;
+    __syncthreads();
+    while (nf != 0) {
+        // opening a subtree replaces one pending record by two: at most `budget` more may be opened
+        const uint32_t budget = kCutCap - (nout + nf);
+        bool have[2], small[2];
+        uint32_t ref[2], count[2], childref[2];
+        float box[2][6];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t e = tid + j * kCutThreads;
+            have[j] = e < nf;
+            small[j] = true, ref[j] = 0, count[j] = 0, childref[j] = 0;
+            if (have[j]) {
+                const uint32_t ent = frontier[cur][e];
+                const uint32_t parent = ent >> 1, side = ent & 1u;
+                const float* nd = nodes + 16 * (size_t)parent;
+                const uint32_t c = __float_as_uint(nd[12 + side]);
+                const uint32_t gamma = __float_as_uint(nd[12]) & 0x7FFFFFFFu;
+                const uint32_t lo = __float_as_uint(nd[14]), hi = __float_as_uint(nd[15]);
+                const uint32_t first = side ? gamma + 1u : lo;
+                count[j] = side ? hi - gamma : gamma - lo + 1u;
+                small[j] = (c & 0x80000000u) || count[j] <= kRangeMax;
+                ref[j] = small[j] ? first : c;
+                childref[j] = c;
+#pragma unroll
+                for (int a = 0; a < 6; a++) box[j][a] = nd[6 * side + a];
+            }
+        }
+        uint32_t o0, o1;
+        block_ranks(have[0] && !small[0], have[1] && !small[1], tot, o0, o1);
+        const bool open0 = have[0] && !small[0] && o0 < budget, open1 = have[1] && !small[1] && o1 < budget;
+        uint32_t e0, e1;
+        const uint32_t emitted = block_ranks(have[0] && !open0, have[1] && !open1, tot, e0, e1);
+        const uint32_t opened = nf - emitted;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const bool open = j ? open1 : open0;
+            if (have[j] && open) {
+                const uint32_t at = 2u * (j ? o1 : o0);
+                frontier[cur ^ 1][at] = 2u * childref[j];
+                frontier[cur ^ 1][at + 1u] = 2u * childref[j] + 1u;
+            } else if (have[j]) {
+                float* r = cut + 8 * (size_t)(nout + (j ? e1 : e0));
+                r[0] = box[j][0], r[1] = box[j][1], r[2] = box[j][2], r[3] = __uint_as_float(ref[j]);
+                r[4] = box[j][3], r[5] = box[j][4], r[6] = box[j][5], r[7] = __uint_as_float(count[j]);
+            }
+        }
+        nout += emitted;
+        nf = 2u * opened;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (tid == 0) *ncut_out = nout;
+    __threadfence_block();
+    __syncthreads(); // the records are read back below by other lanes of this workgroup
     // boxes of kCutGroup consecutive records (breadth-first order keeps neighbours together): 8 floats per group
-    for (uint32_t g = 0; g * kCutGroup < nout; g++) {
+    for (uint32_t g = tid; g * kCutGroup < nout; g += kCutThreads) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (uint32_t i = g * kCutGroup; i < nout && i < (g + 1) * kCutGroup; i++)
             for (int a = 0; a < 3; a++) {
@@ -506,7 +587,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     HIP_RET(tmp.alloc(&scan_totals, ((size_t)ntiles * 256 / kScanBlock + 2) * 4));
     HIP_RET(tmp.alloc(&ready[0], (size_t)(n - 1) * 4));
     HIP_RET(tmp.alloc(&ready[1], (size_t)(n - 1) * 4));
-    HIP_RET(tmp.alloc(&ready_count, 256)); // one counter per level parity, 128 bytes apart
+    HIP_RET(tmp.alloc(&ready_count, (kMaxLevels + 1) * 4)); // one counter per tree level
     HIP_RET(tmp.alloc(&union_box, (size_t)(n - 1) * 32));
     // persistent results
     HIP_RET(hipMalloc((void**)&sc.morton, (size_t)n * 8));
@@ -517,8 +598,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     HIP_RET(hipMalloc((void**)&sc.nodes, (size_t)(n - 1) * 64));
     HIP_RET(hipMalloc((void**)&sc.cut, (size_t)kCutCap * 32));
     HIP_RET(hipMalloc((void**)&sc.cut_groups, (size_t)(kCutCap / kCutGroup) * 32));
-    uint32_t *cut_queue, *d_ncut;
-    HIP_RET(tmp.alloc(&cut_queue, (size_t)kCutCap * 8));
+    uint32_t* d_ncut;
     HIP_RET(tmp.alloc(&d_ncut, 16));
     HIP_RET(hipMalloc((void**)&A1, (size_t)n * 16));
     HIP_RET(hipMalloc((void**)&B1, (size_t)n * 16));
@@ -555,27 +635,32 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        sc.nodes);
     HIP_RET(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, s));
-    HIP_RET(hipMemsetAsync(ready_count, 0, 256, s));
+    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 1) * 4, s));
     hipLaunchKernelGGL(k_refit_leaves, grid_n, blk, 0, s, n, sc.leaf_parent, arrive, ready[0], ready_count);
     HIP_RET(hipGetLastError());
-    uint32_t finished = 0;
-    for (int level = 0;; level++) { // one launch per level; the level's size comes back to the host
-        const int cur = level & 1;
-        uint32_t nready = 0;
-        HIP_RET(hipMemcpyAsync(&nready, ready_count + 32 * cur, 4, hipMemcpyDeviceToHost, s));
+    // One launch per tree level; level L reads its size from ready_count[L] on the device and appends the nodes that
+    // become ready to level L + 1.  The host queues eight levels at a time and then looks at the counters.
+    const dim3 grid_level(std::min<uint32_t>((n + 255) / 256, 2048));
+    uint32_t level_count[kMaxLevels + 1];
+    uint32_t level = 0;
+    for (;;) {
+        for (int i = 0; i < 8 && level < kMaxLevels; i++, level++) {
+            const int cur = (int)(level & 1u);
+            hipLaunchKernelGGL(k_refit_level, grid_level, blk, 0, s, (const float4*)A1, (const float4*)B1,
+                               (const float4*)C1, sc.child, sc.parent, ready[cur], ready_count + level, arrive, union_box,
+                               sc.nodes, ready[cur ^ 1], ready_count + level + 1);
+        }
+        HIP_RET(hipMemcpyAsync(level_count, ready_count, (level + 1) * 4, hipMemcpyDeviceToHost, s));
         HIP_RET(hipStreamSynchronize(s));
-        if (nready == 0) break;
-        finished += nready;
-        HIP_RET(hipMemsetAsync(ready_count + 32 * (cur ^ 1), 0, 4, s));
-        hipLaunchKernelGGL(k_refit_level, dim3((nready + 255) / 256), blk, 0, s, (const float4*)A1, (const float4*)B1,
-                           (const float4*)C1, sc.child, sc.parent, ready[cur], nready, arrive, union_box, sc.nodes,
-                           ready[cur ^ 1], ready_count + 32 * (cur ^ 1));
-        if (level > 200) return hipErrorUnknown; // a tree over 63+32-bit keys is at most 96 levels deep
+        if (level_count[level] == 0) break; // nothing is waiting for another level
+        if (level >= kMaxLevels) return hipErrorUnknown; // a tree over 63+32-bit keys is at most 96 levels deep
     }
+    uint64_t finished = 0;
+    for (uint32_t l = 0; l < level; l++) finished += level_count[l];
     if (finished != n - 1) return hipErrorUnknown; // every internal node must have been refitted
     HIP_RET(hipGetLastError());
-    hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(1), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups, d_ncut,
-                       cut_queue);
+    hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
+                       d_ncut);
     HIP_RET(hipGetLastError());
     HIP_RET(hipMemcpyAsync(&sc.ncut, d_ncut, 4, hipMemcpyDeviceToHost, s));
     HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
