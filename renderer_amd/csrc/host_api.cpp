@@ -67,8 +67,9 @@ void dfree(T*& p) {
 }
 
 void free_device_scene(DeviceScene& d) {
-    dfree(d.xyzw), dfree(d.idx), dfree(d.triA), dfree(d.triB), dfree(d.triC);
-    dfree(d.morton), dfree(d.order), dfree(d.child), dfree(d.parent), dfree(d.leaf_parent), dfree(d.nodes), dfree(d.cut), dfree(d.cut_groups);
+    dfree(d.arena); // every array of the scene lives in this one allocation
+    d.xyzw = nullptr, d.idx = nullptr, d.triA = d.triB = d.triC = nullptr;
+    d.morton = nullptr, d.order = d.child = d.parent = d.leaf_parent = nullptr, d.nodes = d.cut = d.cut_groups = nullptr;
 }
 
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).
@@ -308,42 +309,57 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         s->vertex_diag = std::sqrt((ex * ex + ey * ey) + ez * ez);
     }
     s->max_abs = max_abs;
-    float* d_tr = nullptr;
+    // Two device allocations per build: what the scene keeps, and what only the build needs.
+    const size_t tri_bytes = Arena::aligned((size_t)d.ntri * 16);
+    const bool tree = d.ntri >= 2;
+    Arena keep, scratch;
+    keep.size = Arena::aligned((size_t)nv * 16) + Arena::aligned((size_t)base_ntri * 12) + 3 * tri_bytes +
+                lbvh_keep_bytes(d.ntri) + 256;
+    scratch.size = (tree ? 3 * tri_bytes + lbvh_scratch_bytes(d.ntri) : 0) + Arena::aligned((size_t)ninst * 12) + 256;
     int rc = INV_OK;
     hipError_t e = hipSuccess;
     auto bail = [&](hipError_t err, const char* what) {
         rc = hip_fail(err, what);
-        if (d_tr) (void)hipFree(d_tr);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (scratch.base) (void)hipFree(scratch.base);
         free_device_scene(d);
         delete s;
         return rc;
     };
+    if ((e = hipMalloc((void**)&keep.base, keep.size)) != hipSuccess) return bail(e, "hipMalloc(scene)");
+    d.arena = keep.base;
+    if ((e = hipMalloc((void**)&scratch.base, scratch.size)) != hipSuccess) return bail(e, "hipMalloc(build scratch)");
     if (nv) {
-        if ((e = hipMalloc((void**)&d.xyzw, (size_t)nv * 16)) != hipSuccess) return bail(e, "hipMalloc(vertices)");
+        d.xyzw = keep.take<float>((size_t)nv * 16);
         // host-visible copy of the Obj arrays (src/invert.cpp:1136-1140, 1161-1164)
         if ((e = hipMemcpyAsync(d.xyzw, mesh->xyzw.data(), (size_t)nv * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return bail(e, "hipMemcpyAsync(vertices)");
     }
     if (base_ntri) {
-        if ((e = hipMalloc((void**)&d.idx, (size_t)base_ntri * 12)) != hipSuccess) return bail(e, "hipMalloc(indices)");
+        d.idx = keep.take<uint32_t>((size_t)base_ntri * 12);
         if ((e = hipMemcpyAsync(d.idx, mesh->idx.data(), (size_t)base_ntri * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return bail(e, "hipMemcpyAsync(indices)");
     }
     if (d.ntri) {
-        if ((e = hipMalloc((void**)&d.triA, (size_t)d.ntri * 16)) != hipSuccess) return bail(e, "hipMalloc(triA)");
-        if ((e = hipMalloc((void**)&d.triB, (size_t)d.ntri * 16)) != hipSuccess) return bail(e, "hipMalloc(triB)");
-        if ((e = hipMalloc((void**)&d.triC, (size_t)d.ntri * 16)) != hipSuccess) return bail(e, "hipMalloc(triC)");
+        d.triA = keep.take<float>((size_t)d.ntri * 16);
+        d.triB = keep.take<float>((size_t)d.ntri * 16);
+        d.triC = keep.take<float>((size_t)d.ntri * 16);
+        // with a tree the assembled triangles are scratch: the build stores them again in Morton order
+        float* A0 = tree ? scratch.take<float>((size_t)d.ntri * 16) : d.triA;
+        float* B0 = tree ? scratch.take<float>((size_t)d.ntri * 16) : d.triB;
+        float* C0 = tree ? scratch.take<float>((size_t)d.ntri * 16) : d.triC;
+        float* d_tr = nullptr;
         if (translations_xyz) {
-            if ((e = hipMalloc((void**)&d_tr, (size_t)ninst * 12)) != hipSuccess) return bail(e, "hipMalloc(translations)");
+            d_tr = scratch.take<float>((size_t)ninst * 12);
             if ((e = hipMemcpyAsync(d_tr, translations_xyz, (size_t)ninst * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
                 return bail(e, "hipMemcpyAsync(translations)");
         }
-        if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, d.triA, d.triB, d.triC)) != hipSuccess)
+        if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0)) != hipSuccess)
             return bail(e, "assemble kernel");
-        if ((e = build_lbvh(ctx->stream, d)) != hipSuccess) return bail(e, "LBVH build");
+        if ((e = build_lbvh(ctx->stream, d, keep, scratch, A0, B0, C0)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
-    if (d_tr) (void)hipFree(d_tr);
+    (void)hipFree(scratch.base);
     *out = s;
     return INV_OK;
 }

@@ -37,7 +37,22 @@ void hit_rect(const FrameK& f, const float bbox[6], uint32_t rect[4]);
 // with its box; subtrees of at most kRangeMax leaves are taken whole as a range of the sorted triangle array.
 constexpr uint32_t kCutCap = 2048, kRangeMax = 16, kCutGroup = 16;
 
+// One device allocation handed out in 256-byte aligned pieces (a scene build makes two: what the scene keeps and
+// what only the build needs).
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+    static size_t aligned(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    template <class T>
+    T* take(size_t bytes) {
+        T* p = (T*)(base + used);
+        used += aligned(bytes ? bytes : 16);
+        return used <= size ? p : nullptr;
+    }
+};
+
 struct DeviceScene {
+    void* arena = nullptr; // every pointer below points into this one allocation
     uint32_t nv = 0, ntri = 0;
     float* xyzw = nullptr;    // nv float4 (mesh vertices as uploaded)
     uint32_t* idx = nullptr;  // 3 * base_ntri indices
@@ -72,7 +87,11 @@ hipError_t launch_deinterleave_sparse(hipStream_t s, const FrameK& f, const uint
                                       uint64_t frame_plane_stride);
 hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
                                uint32_t* frame);
-// LBVH build over triA/B/C (reorders them into Morton order); scratch is allocated and freed inside.
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc);
+// LBVH build over the assembled triangles A0/B0/C0: fills sc.triA/B/C (Morton order) and the tree arrays from
+// `keep`, temporaries from `scratch` (sizes from the two functions below).  Synchronises the stream once at the end.
+size_t lbvh_keep_bytes(uint32_t ntri);
+size_t lbvh_scratch_bytes(uint32_t ntri);
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* A0, const float* B0,
+                      const float* C0);
 
 } // namespace inv

@@ -375,11 +375,26 @@ __device__ __forceinline__ void arrive_at(bool live, uint32_t node, uint32_t* __
     if (second) next[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = node;
 }
 
-__global__ __launch_bounds__(256) void k_refit_leaves(uint32_t n, const uint32_t* __restrict__ leaf_parent,
+// The leaves' arrivals need no atomics: how many of a node's children are leaves is in its child references.
+// Sets every arrival counter to that number and lists the nodes over two leaves as the first level.
+__global__ __launch_bounds__(256) void k_refit_leaves(uint32_t ninternal, const uint32_t* __restrict__ child,
                                                       uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
                                                       uint32_t* __restrict__ next_count) {
-    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    arrive_at(leaf < n, leaf < n ? leaf_parent[leaf] : 0xFFFFFFFFu, arrive, next, next_count);
+    const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t leaves = 0;
+    if (node < ninternal) {
+        leaves = (child[2 * (size_t)node] >> 31) + (child[2 * (size_t)node + 1] >> 31);
+        arrive[node] = leaves;
+    }
+    const bool ready = leaves == 2u;
+    const uint64_t mask = __ballot(ready);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (ready) next[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = node;
 }
 
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
@@ -551,60 +566,62 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
         if (e_ != hipSuccess) return e_;  \
     } while (0)
 
-struct Scratch {
-    std::vector<void*> ptrs;
-    ~Scratch() {
-        for (void* p : ptrs) (void)hipFree(p);
-    }
-    template <class T>
-    hipError_t alloc(T** p, size_t bytes) {
-        hipError_t e = hipMalloc((void**)p, bytes ? bytes : 16);
-        if (e == hipSuccess) ptrs.push_back(*p);
-        return e;
-    }
-};
-
 } // namespace
 
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
+static uint32_t bounds_blocks_for(uint32_t n) { return std::min<uint32_t>((n + 255) / 256, 1024); }
+static uint32_t sort_tiles_for(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+
+size_t lbvh_keep_bytes(uint32_t n) {
+    if (n < 2) return 0;
+    const size_t sizes[] = {(size_t)n * 8, (size_t)n * 4, (size_t)(n - 1) * 8, (size_t)(n - 1) * 4, (size_t)n * 4,
+                            (size_t)(n - 1) * 64, (size_t)kCutCap * 32, (size_t)(kCutCap / kCutGroup) * 32};
+    size_t total = 0;
+    for (size_t b : sizes) total += Arena::aligned(b);
+    return total;
+}
+
+size_t lbvh_scratch_bytes(uint32_t n) {
+    if (n < 2) return 0;
+    const size_t ntiles = sort_tiles_for(n);
+    const size_t sizes[] = {(size_t)bounds_blocks_for(n) * 24, 32, (size_t)n * 8, (size_t)n * 4, ntiles * 256 * 4,
+                            (size_t)(n - 1) * 4, (ntiles * 256 / kScanBlock + 2) * 4, (size_t)(n - 1) * 4,
+                            (size_t)(n - 1) * 4, (kMaxLevels + 1) * 4, (size_t)(n - 1) * 32, 16};
+    size_t total = 0;
+    for (size_t b : sizes) total += Arena::aligned(b);
+    return total;
+}
+
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* A0f, const float* B0f,
+                      const float* C0f) {
     const uint32_t n = sc.ntri;
     sc.has_bvh = false;
     if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
-    Scratch tmp;
-    const uint32_t bounds_blocks = std::min<uint32_t>((n + 255) / 256, 1024);
-    const uint32_t ntiles = (n + kSortTile - 1) / kSortTile;
-    float *partial, *d_bbox, *union_box;
-    uint64_t* keys_alt;
-    uint32_t *vals_alt, *counts, *arrive;
-    float4 *A1, *B1, *C1;
-    HIP_RET(tmp.alloc(&partial, (size_t)bounds_blocks * 24));
-    HIP_RET(tmp.alloc(&d_bbox, 32));
-    HIP_RET(tmp.alloc(&keys_alt, (size_t)n * 8));
-    HIP_RET(tmp.alloc(&vals_alt, (size_t)n * 4));
-    HIP_RET(tmp.alloc(&counts, (size_t)ntiles * 256 * 4));
-    HIP_RET(tmp.alloc(&arrive, (size_t)(n - 1) * 4));
-    uint32_t *scan_totals, *ready[2], *ready_count;
-    HIP_RET(tmp.alloc(&scan_totals, ((size_t)ntiles * 256 / kScanBlock + 2) * 4));
-    HIP_RET(tmp.alloc(&ready[0], (size_t)(n - 1) * 4));
-    HIP_RET(tmp.alloc(&ready[1], (size_t)(n - 1) * 4));
-    HIP_RET(tmp.alloc(&ready_count, (kMaxLevels + 1) * 4)); // one counter per tree level
-    HIP_RET(tmp.alloc(&union_box, (size_t)(n - 1) * 32));
-    // persistent results
-    HIP_RET(hipMalloc((void**)&sc.morton, (size_t)n * 8));
-    HIP_RET(hipMalloc((void**)&sc.order, (size_t)n * 4));
-    HIP_RET(hipMalloc((void**)&sc.child, (size_t)(n - 1) * 8));
-    HIP_RET(hipMalloc((void**)&sc.parent, (size_t)(n - 1) * 4));
-    HIP_RET(hipMalloc((void**)&sc.leaf_parent, (size_t)n * 4));
-    HIP_RET(hipMalloc((void**)&sc.nodes, (size_t)(n - 1) * 64));
-    HIP_RET(hipMalloc((void**)&sc.cut, (size_t)kCutCap * 32));
-    HIP_RET(hipMalloc((void**)&sc.cut_groups, (size_t)(kCutCap / kCutGroup) * 32));
-    uint32_t* d_ncut;
-    HIP_RET(tmp.alloc(&d_ncut, 16));
-    HIP_RET(hipMalloc((void**)&A1, (size_t)n * 16));
-    HIP_RET(hipMalloc((void**)&B1, (size_t)n * 16));
-    HIP_RET(hipMalloc((void**)&C1, (size_t)n * 16));
+    const uint32_t bounds_blocks = bounds_blocks_for(n);
+    const uint32_t ntiles = sort_tiles_for(n);
+    float* partial = tmp.take<float>((size_t)bounds_blocks * 24);
+    float* d_bbox = tmp.take<float>(32);
+    uint64_t* keys_alt = tmp.take<uint64_t>((size_t)n * 8);
+    uint32_t* vals_alt = tmp.take<uint32_t>((size_t)n * 4);
+    uint32_t* counts = tmp.take<uint32_t>((size_t)ntiles * 256 * 4);
+    uint32_t* arrive = tmp.take<uint32_t>((size_t)(n - 1) * 4);
+    uint32_t* scan_totals = tmp.take<uint32_t>(((size_t)ntiles * 256 / kScanBlock + 2) * 4);
+    uint32_t* ready[2] = {tmp.take<uint32_t>((size_t)(n - 1) * 4), tmp.take<uint32_t>((size_t)(n - 1) * 4)};
+    uint32_t* ready_count = tmp.take<uint32_t>((kMaxLevels + 1) * 4); // one counter per tree level
+    float* union_box = tmp.take<float>((size_t)(n - 1) * 32);
+    uint32_t* d_ncut = tmp.take<uint32_t>(16);
+    // what the scene keeps
+    sc.morton = keep.take<uint64_t>((size_t)n * 8);
+    sc.order = keep.take<uint32_t>((size_t)n * 4);
+    sc.child = keep.take<uint32_t>((size_t)(n - 1) * 8);
+    sc.parent = keep.take<uint32_t>((size_t)(n - 1) * 4);
+    sc.leaf_parent = keep.take<uint32_t>((size_t)n * 4);
+    sc.nodes = keep.take<float>((size_t)(n - 1) * 64);
+    sc.cut = keep.take<float>((size_t)kCutCap * 32);
+    sc.cut_groups = keep.take<float>((size_t)(kCutCap / kCutGroup) * 32);
+    if (!d_ncut || !sc.cut_groups) return hipErrorOutOfMemory; // the arenas were sized for something else
+    float4 *A1 = (float4*)sc.triA, *B1 = (float4*)sc.triB, *C1 = (float4*)sc.triC;
 
-    const float4 *A0 = (const float4*)sc.triA, *B0 = (const float4*)sc.triB, *C0 = (const float4*)sc.triC;
+    const float4 *A0 = (const float4*)A0f, *B0 = (const float4*)B0f, *C0 = (const float4*)C0f;
     const dim3 blk(256), grid_n((n + 255) / 256);
     hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_blocks), blk, 0, s, A0, B0, C0, n, partial);
     hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, bounds_blocks, d_bbox);
@@ -634,9 +651,9 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, A0, B0, C0, sc.order, n, A1, B1, C1);
     hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        sc.nodes);
-    HIP_RET(hipMemsetAsync(arrive, 0, (size_t)(n - 1) * 4, s));
     HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 1) * 4, s));
-    hipLaunchKernelGGL(k_refit_leaves, grid_n, blk, 0, s, n, sc.leaf_parent, arrive, ready[0], ready_count);
+    hipLaunchKernelGGL(k_refit_leaves, dim3((n - 1 + 255) / 256), blk, 0, s, n - 1, sc.child, arrive, ready[0],
+                       ready_count);
     HIP_RET(hipGetLastError());
     // One launch per tree level; level L reads its size from ready_count[L] on the device and appends the nodes that
     // become ready to level L + 1.  The host queues eight levels at a time and then looks at the counters.
@@ -665,9 +682,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc) {
     HIP_RET(hipMemcpyAsync(&sc.ncut, d_ncut, 4, hipMemcpyDeviceToHost, s));
     HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
     HIP_RET(hipMemcpyAsync(&sc.height, union_box + 6, 4, hipMemcpyDeviceToHost, s)); // root height
-    HIP_RET(hipStreamSynchronize(s)); // scratch is freed on return
-    (void)hipFree(sc.triA), (void)hipFree(sc.triB), (void)hipFree(sc.triC);
-    sc.triA = (float*)A1, sc.triB = (float*)B1, sc.triC = (float*)C1;
+    HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
     sc.has_bvh = true;
     return hipSuccess;
 }
