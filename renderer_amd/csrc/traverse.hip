@@ -283,7 +283,8 @@ struct TileLds {
     } u;
     float srgb[256];             // copy of the sRGB threshold table
     unsigned long long best[64]; // per pixel: smallest (depth, primitive) key of the current sample
-    float4 win[64];              // per pixel: (un, vn, det, record slot) of the lane that holds the winning key
+    float4 win[NW * 64];         // per pixel: (un, vn, det, record slot) of the lane that holds the winning key;
+                                 // or, when waves split the samples, the colour of each wave's sample
     float win_t[64];             // and its ray parameter
     uint32_t groups[kCutCap / kCutGroup]; // cut groups whose box meets the tile's frustum
     uint32_t n_groups;
@@ -515,7 +516,46 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
     float sr = 0.0f, sg = 0.0f, sb = 0.0f; // first wave only
     Hit first = miss_hit();
     const Ray ray0 = make_ray(f, px, py, 0.5f, 0.5f);
-    for (uint32_t s = 0; s < f.spp; s++) {
+    // With at least one sample per wave the waves split the samples instead of the records: a wave carries its
+    // sample through every record and shades it itself, so there is no per-sample exchange between waves; the
+    // first wave adds the colours up in sample order, NW samples per round.
+    const bool by_sample = !BATCHED && f.spp >= (uint32_t)NW;
+    for (uint32_t s0 = 0; by_sample && s0 < f.spp; s0 += NW) { // block-uniform
+        const uint32_t s = s0 + wave;
+        if (s < f.spp) {
+            float sx, sy;
+            sample_offset(pix, s, f.seed, sx, sy);
+            const Ray ray = make_ray(f, px, py, sx, sy);
+            Hit best = miss_hit();
+            const uint32_t nrec = S.n_rec;
+            for (uint32_t c = 0; c < nrec; c += 64) { // 64 records per mask
+                const uint32_t m = min(64u, nrec - c);
+                uint64_t inside = 0;
+                for (uint32_t i = 0; i < m; i++)
+                    inside |= (uint64_t)mt_inside(ray, S.u.t.rec[c + i][0], S.u.t.rec[c + i][1], S.u.t.rec[c + i][2]) << i;
+                while (inside) {
+                    const uint32_t j = c + (uint32_t)__ffsll((long long)inside) - 1u;
+                    inside &= inside - 1ull;
+                    mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], j, best);
+                }
+            }
+            float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
+            if (best.key != kMissKey)
+                shade_hit(f, best, S.u.t.rec[best.slot][0], S.u.t.rec[best.slot][1], S.u.t.rec[best.slot][2], r, g, b);
+            S.win[wave * 64u + lane] = make_float4(r, g, b, 0.0f);
+            if (s == 0) first = best; // sample 0 is the first wave's
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t n = min((uint32_t)NW, f.spp - s0);
+            for (uint32_t w = 0; w < n; w++) {
+                const float4 c = S.win[w * 64u + lane];
+                sr = sr + c.x, sg = sg + c.y, sb = sb + c.z;
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t s = 0; !by_sample && s < f.spp; s++) {
         float sx, sy;
         sample_offset(pix, s, f.seed, sx, sy);
         const Ray ray = make_ray(f, px, py, sx, sy);
