@@ -84,6 +84,32 @@ __device__ __forceinline__ bool mt_inside(const Ray& r, const float4& A, const f
     return (det > 0.0f) & !(un < 0.0f) & !(un > det) & !(vn < 0.0f) & !(un + vn > det);
 }
 
+// The same decision from terms folded once per triangle, for rays that share the origin o (every primary ray
+// does): with t = o - v0,  det = e1 . (d x e2) = d . (e2 x e1),  un = t . (d x e2) = d . (e2 x t),  vn = d . (t x e1).
+// vn is computed exactly as mt_test computes it; det and un differ from mt_test's values by rounding only, so
+// the comparisons that involve them are widened by `eps` (many times that rounding): the result is true wherever
+// mt_inside is true and almost nowhere else.  P0 = (e2 x e1, eps), P1 = (e2 x t, 0), P2 = (t x e1, 0).
+__device__ __forceinline__ void fold_triangle(float ox, float oy, float oz, float dmax, const float4& A, const float4& B,
+                                              const float4& C, float4& P0, float4& P1, float4& P2) {
+    const float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
+    P0.x = C.y * B.z - C.z * B.y, P0.y = C.z * B.x - C.x * B.z, P0.z = C.x * B.y - C.y * B.x;
+    P1.x = C.y * tz - C.z * ty, P1.y = C.z * tx - C.x * tz, P1.z = C.x * ty - C.y * tx;
+    P2.x = ty * B.z - tz * B.y, P2.y = tz * B.x - tx * B.z, P2.z = tx * B.y - ty * B.x; // mt_test's qvec
+    const float c1 = (fabsf(C.x) + fabsf(C.y)) + fabsf(C.z);
+    const float b1 = (fabsf(B.x) + fabsf(B.y)) + fabsf(B.z), t1 = (fabsf(tx) + fabsf(ty)) + fabsf(tz);
+    // every product in det and un is below dmax * c1 * max(b1, t1); a dozen roundings of 2^-24 each
+    P0.w = 0x1p-18f * (dmax * c1) * fmaxf(b1, t1);
+    P1.w = 0.0f, P2.w = 0.0f;
+}
+
+__device__ __forceinline__ bool mt_inside_folded(const Ray& r, const float4& P0, const float4& P1, const float4& P2) {
+    const float det = (r.dx * P0.x + r.dy * P0.y) + r.dz * P0.z;
+    const float un = (r.dx * P1.x + r.dy * P1.y) + r.dz * P1.z;
+    const float vn = (r.dx * P2.x + r.dy * P2.y) + r.dz * P2.z;
+    const float e = P0.w, hi = det + (e + e);
+    return (det > -e) & !(un < -e) & !(un > hi) & !(vn < 0.0f) & !(un + vn > hi);
+}
+
 // Triangle record: three float4
 //   A = (v0.xyz, primitive id bits)   B = (e1.xyz, z of vertex 1)   C = (e2.xyz, z of vertex 2)
 // with e1 = v1 - v0, e2 = v2 - v0 rounded once at assembly.

@@ -278,6 +278,7 @@ struct TileLds {
             uint32_t frontier[2][kFrontierCap];
             uint2 ranges[kRangeCap];      // (first sorted triangle, count <= kRangeMax)
             float4 rec[kTileCap][3];      // candidate records A, B, C that survived the per-triangle test
+            float4 pre[kTileCap][3];      // their folded terms for the cheap inside test (fold_triangle)
         } t;
         uint32_t stack[kStack * 64]; // fallback: per-lane traversal by the first wave
     } u;
@@ -444,6 +445,12 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
         dir_at(f, (float)(tx0 + 8u) + m, (float)ty0 - m, cdx[1], cdy[1], cdz[1]);
         dir_at(f, (float)tx0 - m, (float)(ty0 + 8u) + m, cdx[2], cdy[2], cdz[2]);
         dir_at(f, (float)(tx0 + 8u) + m, (float)(ty0 + 8u) + m, cdx[3], cdy[3], cdz[3]);
+        // bound on |direction component| over the tile's samples: directions are affine in the sample position, so
+        // the corners of the grown tile bound them (doubled: make_ray's own roundings are nowhere near that)
+        float dabs = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) dabs = fmaxf(dabs, fmaxf(fmaxf(fabsf(cdx[c]), fabsf(cdy[c])), fabsf(cdz[c])));
+        dabs = dabs + dabs;
         const uint32_t nslots = (r1 - r0) * kRangeMax;
         for (uint32_t base = 0; base < nslots; base += NT) { // block-uniform trip count
             const uint32_t q = base + tid;
@@ -480,6 +487,11 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                     S.u.t.rec[at][0] = A;
                     S.u.t.rec[at][1] = B;
                     S.u.t.rec[at][2] = C;
+                    float4 P0, P1, P2;
+                    fold_triangle(f.ox, f.oy, f.oz, dabs, A, B, C, P0, P1, P2);
+                    S.u.t.pre[at][0] = P0;
+                    S.u.t.pre[at][1] = P1;
+                    S.u.t.pre[at][2] = P2;
                     if (BATCHED) S.rec_k[at] = k;
                 } else {
                     S.rec_overflow = 1;
@@ -532,7 +544,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                 const uint32_t m = min(64u, nrec - c);
                 uint64_t inside = 0;
                 for (uint32_t i = 0; i < m; i++)
-                    inside |= (uint64_t)mt_inside(ray, S.u.t.rec[c + i][0], S.u.t.rec[c + i][1], S.u.t.rec[c + i][2]) << i;
+                    inside |= (uint64_t)mt_inside_folded(ray, S.u.t.pre[c + i][0], S.u.t.pre[c + i][1], S.u.t.pre[c + i][2]) << i;
                 while (inside) {
                     const uint32_t j = c + (uint32_t)__ffsll((long long)inside) - 1u;
                     inside &= inside - 1ull;
@@ -572,7 +584,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
             // cheap pass: which of this wave's records contain the sample (one bit per record, no divergence) ...
             uint64_t inside = 0;
             for (uint32_t j = wave, i = 0; j < nrec; j += NW, i++)
-                inside |= (uint64_t)mt_inside(ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2]) << i;
+                inside |= (uint64_t)mt_inside_folded(ray, S.u.t.pre[j][0], S.u.t.pre[j][1], S.u.t.pre[j][2]) << i;
             // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
             while (inside) {
                 const uint32_t i = (uint32_t)__ffsll((long long)inside) - 1u;
