@@ -35,6 +35,10 @@ namespace {
 // timing-only switches in the high flag bits (images are wrong when set; used by tools/phase_timing.py)
 constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDebugSkipAll = 1u << 22, kDebugCounts = 1u << 23;
 
+#ifndef INV_AO_REFILL
+#define INV_AO_REFILL 32
+#endif
+constexpr int kAoRefill = INV_AO_REFILL; // idle lanes at which a wave takes new rays
 constexpr unsigned long long kAoChunk = 64; // occlusion rays per chunk; chunks are dealt round-robin to the waves
 constexpr int kStack = 40;        // per-lane stack entries; deeper trees use the brute-force kernel
 constexpr int kFrontierCap = 256;  // nodes per breadth-first level kept in LDS
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
     RaySlabs rs = {};
     for (;;) {
         const uint64_t idle = __ballot(!active);
-        if (more && __popcll(idle) >= 16) {
+        if (more && __popcll(idle) >= kAoRefill) {
             if (cur == end) { // next chunk of this wave: chunks are dealt round-robin over the grid's waves
                 const uint64_t base = chunk * kAoChunk;
                 chunk += nwaves;
@@ -823,13 +827,14 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
             const float4 q0 = nodes[4 * (size_t)node + 0], q1 = nodes[4 * (size_t)node + 1];
             const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
             const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            float tn;
-            const bool h0 = slab_folded(rs, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlim, tn);
-            const bool h1 = slab_folded(rs, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlim, tn);
-            if (h0 && h1) {
-                stack[(size_t)sp * 256] = c1;
+            float tn0, tn1;
+            const bool h0 = slab_folded(rs, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlim, tn0);
+            const bool h1 = slab_folded(rs, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlim, tn1);
+            if (h0 && h1) { // nearer child first: an occluder close to the surface ends the ray soonest
+                const bool first1 = tn1 < tn0;
+                stack[(size_t)sp * 256] = first1 ? c0 : c1;
                 sp++;
-                node = c0;
+                node = first1 ? c1 : c0;
             } else if (h0) {
                 node = c0;
             } else if (h1) {

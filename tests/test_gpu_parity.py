@@ -77,6 +77,18 @@ def test_jittered_samples_against_oracle(oracle, bunny_scene, bunny_mesh, brute)
     common.assert_frames_equal(got, want, "spp=4")
 
 
+@pytest.mark.parametrize("spp", [2, 4, 5, 8])
+def test_samples_in_the_sparse_scene_tile_kernel(oracle, bunny_scene, bunny_mesh, spp):
+    """720p keeps the bunny's triangles larger than a pixel (the variant of the tile kernel that holds a tile's
+    candidates at once): below four samples the waves share each sample's records, from four on each wave carries
+    whole samples (5: a last round with one wave busy)."""
+    w, h = 1280, 720
+    prm = R.make_params(w, h, spp=spp, seed=5, flags=R.LAMBERT | R.INVERT)
+    got = bunny_scene.render(R.camera_reference(w, h), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "spp=%d" % spp)
+
+
 @pytest.mark.parametrize("size", [(1, 1), (7, 5), (64, 64), (129, 65), (1000, 3)])
 def test_odd_extents(oracle, bunny_scene, bunny_mesh, size):
     w, h = size
@@ -290,8 +302,8 @@ def test_lbvh_structure_random(oracle, gpu_ctx, ntri, seed):
 
 @pytest.mark.parametrize("ntri,size", [(700, 0.02), (6000, 0.03)])
 def test_tile_kernel_list_overflow_paths(oracle, gpu_ctx, ntri, size):
-    """Dense overlapping soups at 64x64: the per-wave list (160) and the per-block list (1024) overflow, so the tile
-    kernel takes its two fallbacks (block list from memory; per-lane traversal)."""
+    """Dense overlapping soups at 64x64: more candidates per 8x8 tile than the record list (256) and, for the larger
+    soup, than the range list holds, so the tile kernel works in batches or hands tiles to the per-lane traversal."""
     xyz, faces = objfmt.random_soup(ntri, seed=9, lo=(-0.02, 0.08, -0.02), hi=(0.02, 0.12, 0.02), size=size)
     xyzw = np.zeros((len(xyz), 4), np.float32)
     xyzw[:, :3] = xyz
