@@ -33,7 +33,7 @@ namespace inv {
 namespace {
 
 // timing-only switches in the high flag bits (images are wrong when set; used by tools/phase_timing.py)
-constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDebugSkipAll = 1u << 22, kDebugCounts = 1u << 23;
+constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDebugSkipAll = 1u << 22, kDebugCounts = 1u << 23, kDebugSkipExact = 1u << 24;
 
 #ifndef INV_AO_REFILL
 #define INV_AO_REFILL 32
@@ -590,6 +590,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
             for (uint32_t j = wave, i = 0; j < nrec; j += NW, i++)
                 inside |= (uint64_t)mt_inside_folded(ray, S.u.t.pre[j][0], S.u.t.pre[j][1], S.u.t.pre[j][2]) << i;
             // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
+            if (f.flags & kDebugSkipExact) inside = 0; // timing experiment only
             while (inside) {
                 const uint32_t i = (uint32_t)__ffsll((long long)inside) - 1u;
                 inside &= inside - 1ull;

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 import objfmt  # noqa: E402
 import renderer_amd as R  # noqa: E402
 
-VARIANTS = [("full", 0), ("no phase 3", 1 << 20), ("no phase 2,3", 1 << 21), ("fill only", 1 << 22),
+VARIANTS = [("full", 0), ("no exact pass", 1 << 24), ("no phase 3", 1 << 20), ("no phase 2,3", 1 << 21), ("fill only", 1 << 22),
             ("lane traversal", R.LANE_TRAVERSAL)]
 
 
