@@ -81,16 +81,18 @@ class SparseComposite:
         else:
             self.planes = torch.empty(3, self.slot_elems, dtype=torch.int32, device=device)
             self._out = self.planes
+        # per-frame calls reuse these instead of rebuilding views and pointers
+        self._ptrs = tuple(self._out[k].data_ptr() for k in range(3))
+        self._parts = list(self.gathered.unbind(0)) if rank == 0 else None
 
     def render(self):
-        o = self._out
-        self.scene.render_device(self.cam, self.prm, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+        self.scene.render_device(self.cam, self.prm, *self._ptrs)
 
     def gather(self):
         if self.slot_elems == 0:
             return  # nothing on screen: rank 0's frame is already complete
         if self.rank == 0:
-            dist.gather(self.planes, list(self.gathered.unbind(0)), dst=0)
+            dist.gather(self.planes, self._parts, dst=0)
         else:
             dist.gather(self.planes, None, dst=0)
 

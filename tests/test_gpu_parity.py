@@ -402,6 +402,27 @@ def test_instanced_scene_small(oracle, gpu_ctx, bunny_path, bunny_mesh, mode):
     scene.close()
 
 
+def test_instanced_scene_with_sub_pixel_triangles(oracle, gpu_ctx, bunny_path, bunny_mesh):
+    """12x12 copies (715 392 triangles) seen from afar at 640x360: several triangles per pixel, so the draw takes the
+    tile kernel that works through a tile's candidates in batches; also with jitter and with occlusion rays.  The
+    build goes through the multi-block scan and many refit levels."""
+    tr = common.grid_translations(12)
+    scene = R.Scene(gpu_ctx, R.Mesh.load_obj(bunny_path), translations=tr)
+    assert scene.counts()[0] == 144 * 4968
+    fx, fi = common.flatten_instances(*bunny_mesh, tr)
+    w, h = 640, 360
+    cam = common.pulled_back_camera(R.camera_reference(w, h), 0.27 * 12)
+    ocam = oracle.Camera.from_buffer_copy(bytes(cam))
+    for kw in (dict(), dict(spp=3, seed=2), dict(ao_rays=8, seed=1)):
+        prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT, **kw)
+        got = scene.render(cam, prm)
+        want = oracle.render_bvh(fx, fi, ocam, _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "12x12 instances %r" % (kw,))
+    hits = got[2] != 0xFFFFFFFF
+    assert hits.sum() > 20000 and len(np.unique(got[2][hits] // 4968)) == 144
+    scene.close()
+
+
 def test_mesh_from_the_general_reader_renders(oracle, gpu_ctx, tmp_path):
     """A free-form OBJ with quads and i/t/n corners through the tolerant reader, rendered against the oracle."""
     xyz, faces = objfmt.icosphere(2, radius=0.06, center=(0.0, 0.11, 0.0))
