@@ -256,6 +256,8 @@ def test_errors(bunny_scene):
     cam = R.camera_reference(64, 64)
     with pytest.raises(R.InvertError):
         bunny_scene.render(cam, R.make_params(64, 64, tile=12))
+    with pytest.raises(R.InvertError):
+        bunny_scene.render(cam, R.make_params(64, 64, flags=1 << 22))  # not an INV_* flag
     cam.proj[1] = 0.5  # not a GLM-style perspective
     with pytest.raises(R.InvertError) as e:
         bunny_scene.render(cam, R.make_params(64, 64))

@@ -6,6 +6,8 @@ The switches live in the high bits of inv_params.flags and make the images wrong
 """
 import argparse
 import os
+
+os.environ["INV_TIMING_SWITCHES"] = "1"  # the library refuses the switches otherwise
 import statistics
 import sys
 

@@ -6,6 +6,8 @@ Uses the diagnostic switches in the high bits of inv_params.flags (images are no
 """
 import argparse
 import os
+
+os.environ["INV_TIMING_SWITCHES"] = "1"  # the library refuses the switches otherwise
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
