@@ -38,13 +38,13 @@ from renderer_amd import dist as RD  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    # the configuration the headline metric is quoted on
     "bunny_1080p_primary_lambert_invert": dict(width=1920, height=1080, spp=1, flags=R.LAMBERT | R.INVERT),
-    # configs[2]: 4K, 16 jittered samples per pixel
+    # 4K, 16 jittered samples per pixel
     "bunny_4k_16spp": dict(width=3840, height=2160, spp=16, flags=R.LAMBERT | R.INVERT),
-    # configs[4]: 64 occlusion rays per hit pixel on top of configs[1]
+    # 64 occlusion rays per hit pixel on top of the headline configuration
     "bunny_1080p_ao64": dict(width=1920, height=1080, spp=1, ao_rays=64, flags=R.LAMBERT | R.INVERT),
-    # parity mode of configs[1]
+    # the headline extent in parity mode (what the reference's shaders draw: no Lambert, no invert)
     "bunny_1080p_parity": dict(width=1920, height=1080, spp=1, flags=0),
 }
 
