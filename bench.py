@@ -5,7 +5,7 @@
 
 One step = one frame of the workload rendered through the C ABI (include/invert.h) with every input
 (triangles, LBVH) and output buffer resident in HBM.  With N > 1 (launched by torch.distributed.run, one
-process per GPU) 64x64 screen tiles are dealt round-robin to the ranks, every rank renders its tiles, and the
+process per GPU) 32x32 screen tiles are dealt round-robin to the ranks, every rank renders its tiles, and the
 three attachments are gathered to rank 0 over RCCL and put together there; the same frame is rendered whatever N
 is, so scaling is "strong".  --composite sparse (default) deals out only the tiles under the scene's projected
 bounds and rank 0 clears the rest of its frame itself; --composite dense deals out and gathers the whole frame.
@@ -129,7 +129,7 @@ def main():
     wl = WORKLOADS[args.workload]
     w, h, spp = wl["width"], wl["height"], wl["spp"]
     flags = wl["flags"] | (R.BRUTE_FORCE if args.brute_force else 0)
-    tile = 64
+    tile = 64 if world == 1 else 32  # several ranks: 32-pixel tiles spread the hit pixels more evenly (1.16 vs 1.62 max/mean at 8)
     # A stream of our own, made torch's current stream: the library launches on it, RCCL orders against it and
     # torch.cuda.Event records on it (a NULL handle would make the library create a private stream).
     stream = torch.cuda.Stream()
