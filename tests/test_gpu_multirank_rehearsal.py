@@ -1,0 +1,41 @@
+"""The N > 1 code path of bench.py on one GPU: two and three ranks share cuda:0 and gather through gloo.
+
+bench.py checks the composited frame against rank 0's own full render before it prints its line, so a zero exit
+status means the tile dealing, the per-rank draws, the gather and the re-assembly agree with the single-GPU frame.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(nranks, *extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nranks), "--steps", "3", "--warmup", "1", "--backend", "gloo", *extra]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=170)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("nranks,extra", [(2, ()), (3, ("--workload", "bunny_1080p_ao64")), (2, ("--composite", "dense"))])
+def test_bench_with_several_ranks_on_one_gpu(nranks, extra):
+    r = _run(nranks, *extra)
+    assert r["n_gpus"] == nranks and r["steps"] == 3 and r["scaling"] == "strong"
+    assert r["value"] > 0 and r["config"]["hit_pixels"] == 25139
+    assert ("dense" if "dense" in extra else "sparse") in r["config"]["parallelism"]
