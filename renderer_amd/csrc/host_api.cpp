@@ -29,6 +29,11 @@ static int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(e_, #expr); \
     } while (0)
 
+// C++ exceptions must not cross the C ABI: entry points that allocate host memory end with this.
+#define INV_CATCH(who)                                                            \
+    catch (const std::bad_alloc&) { return fail(INV_ERR_NOMEM, who ": out of host memory"); } \
+    catch (...) { return fail(INV_ERR_ARG, who ": unexpected C++ exception"); }
+
 } // namespace inv
 
 using namespace inv;
@@ -171,7 +176,7 @@ int inv_ctx_synchronize(inv_ctx* ctx) {
 }
 
 // ---- mesh ----------------------------------------------------------------------------------------
-int inv_mesh_parse_obj(const char* text, uint64_t size, inv_mesh** out) {
+int inv_mesh_parse_obj(const char* text, uint64_t size, inv_mesh** out) try {
     if (!out) return fail(INV_ERR_ARG, "inv_mesh_parse_obj: out is null");
     *out = nullptr;
     inv_mesh* m = new (std::nothrow) inv_mesh;
@@ -184,8 +189,9 @@ int inv_mesh_parse_obj(const char* text, uint64_t size, inv_mesh** out) {
     *out = m;
     return INV_OK;
 }
+INV_CATCH("inv_mesh_parse_obj")
 
-int inv_mesh_load_obj(const char* path, inv_mesh** out) {
+int inv_mesh_load_obj(const char* path, inv_mesh** out) try {
     if (!out) return fail(INV_ERR_ARG, "inv_mesh_load_obj: out is null");
     *out = nullptr;
     if (!path) return fail(INV_ERR_ARG, "inv_mesh_load_obj: path is null");
@@ -200,8 +206,9 @@ int inv_mesh_load_obj(const char* path, inv_mesh** out) {
     if (bad) return fail(INV_ERR_IO, std::string("inv_mesh_load_obj: read error on ") + path);
     return inv_mesh_parse_obj(text.data(), text.size(), out);
 }
+INV_CATCH("inv_mesh_load_obj")
 
-int inv_mesh_load_obj_general(const char* path, inv_mesh** out) {
+int inv_mesh_load_obj_general(const char* path, inv_mesh** out) try {
     if (!out) return fail(INV_ERR_ARG, "inv_mesh_load_obj_general: out is null");
     *out = nullptr;
     if (!path) return fail(INV_ERR_ARG, "inv_mesh_load_obj_general: path is null");
@@ -224,8 +231,9 @@ int inv_mesh_load_obj_general(const char* path, inv_mesh** out) {
     *out = m;
     return INV_OK;
 }
+INV_CATCH("inv_mesh_load_obj_general")
 
-int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t nidx, inv_mesh** out) {
+int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t nidx, inv_mesh** out) try {
     if (!out) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: out is null");
     *out = nullptr;
     if ((nv && !xyzw) || (nidx && !idx)) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: null array");
@@ -239,6 +247,7 @@ int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, ui
     *out = m;
     return INV_OK;
 }
+INV_CATCH("inv_mesh_from_arrays")
 
 int inv_mesh_counts(const inv_mesh* mesh, uint32_t* nv, uint32_t* nidx) {
     if (!mesh) return fail(INV_ERR_ARG, "inv_mesh_counts: mesh is null");
@@ -265,7 +274,7 @@ int inv_camera_reference(uint32_t width, uint32_t height, inv_camera* cam) {
 
 // ---- scene ---------------------------------------------------------------------------------------
 int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* translations_xyz, uint32_t ninst,
-                              inv_scene** out) {
+                              inv_scene** out) try {
     if (!out) return fail(INV_ERR_ARG, "inv_scene_build: out is null");
     *out = nullptr;
     if (!ctx || !mesh) return fail(INV_ERR_ARG, "inv_scene_build: ctx or mesh is null");
@@ -363,6 +372,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     *out = s;
     return INV_OK;
 }
+INV_CATCH("inv_scene_build_instanced")
 
 int inv_scene_build(inv_ctx* ctx, const inv_mesh* mesh, inv_scene** out) {
     return inv_scene_build_instanced(ctx, mesh, nullptr, 1, out);
