@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "internal.h"
@@ -179,14 +180,10 @@ int inv_ctx_synchronize(inv_ctx* ctx) {
 int inv_mesh_parse_obj(const char* text, uint64_t size, inv_mesh** out) try {
     if (!out) return fail(INV_ERR_ARG, "inv_mesh_parse_obj: out is null");
     *out = nullptr;
-    inv_mesh* m = new (std::nothrow) inv_mesh;
-    if (!m) return fail(INV_ERR_NOMEM, "inv_mesh_parse_obj: out of memory");
+    std::unique_ptr<inv_mesh> m(new inv_mesh);
     int rc = parse_obj_text(text, size, m->xyzw, m->idx);
-    if (rc != INV_OK) {
-        delete m;
-        return rc;
-    }
-    *out = m;
+    if (rc != INV_OK) return rc;
+    *out = m.release();
     return INV_OK;
 }
 INV_CATCH("inv_mesh_parse_obj")
@@ -221,14 +218,10 @@ int inv_mesh_load_obj_general(const char* path, inv_mesh** out) try {
     bool bad = std::ferror(fp) != 0;
     std::fclose(fp);
     if (bad) return fail(INV_ERR_IO, std::string("inv_mesh_load_obj_general: read error on ") + path);
-    inv_mesh* m = new (std::nothrow) inv_mesh;
-    if (!m) return fail(INV_ERR_NOMEM, "inv_mesh_load_obj_general: out of memory");
+    std::unique_ptr<inv_mesh> m(new inv_mesh);
     int rc = parse_obj_general(text.data(), text.size(), m->xyzw, m->idx);
-    if (rc != INV_OK) {
-        delete m;
-        return rc;
-    }
-    *out = m;
+    if (rc != INV_OK) return rc;
+    *out = m.release();
     return INV_OK;
 }
 INV_CATCH("inv_mesh_load_obj_general")
@@ -240,11 +233,10 @@ int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, ui
     if (nidx % 3u) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: nidx must be a multiple of 3 (triangle list)");
     for (uint32_t i = 0; i < nidx; i++)
         if (idx[i] >= nv) return fail(INV_ERR_ARG, "inv_mesh_from_arrays: index out of range");
-    inv_mesh* m = new (std::nothrow) inv_mesh;
-    if (!m) return fail(INV_ERR_NOMEM, "inv_mesh_from_arrays: out of memory");
+    std::unique_ptr<inv_mesh> m(new inv_mesh);
     m->xyzw.assign(xyzw, xyzw + (size_t)nv * 4);
     m->idx.assign(idx, idx + nidx);
-    *out = m;
+    *out = m.release();
     return INV_OK;
 }
 INV_CATCH("inv_mesh_from_arrays")
