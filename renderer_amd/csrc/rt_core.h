@@ -178,29 +178,38 @@ __device__ __forceinline__ uint32_t srgb8(float x, const float* T) {
     return (uint32_t)k;
 }
 
-// fragmentShader + interpolated vertex colour (src/shader.slang:27, 31-36), optional Lambert term.
-// A, B, C are the winning triangle's records.
-__device__ __forceinline__ void shade_hit(const FrameK& f, const Hit& h, const float4& A, const float4& B,
-                                          const float4& C, float& r, float& g, float& b) {
+// Lambert factor of a triangle: max(0, unit geometric normal . direction towards the light); it depends on the
+// triangle only, so the tile kernel computes it once per candidate record instead of once per shaded sample.
+__device__ __forceinline__ float lambert_term(const FrameK& f, const float4& B, const float4& C) {
+    float nx = B.y * C.z - B.z * C.y;
+    float ny = B.z * C.x - B.x * C.z;
+    float nz = B.x * C.y - B.y * C.x;
+    float nn = (nx * nx + ny * ny) + nz * nz;
+    float L = 0.0f;
+    if (nn > 0.0f) {
+        float inv = 1.0f / sqrtf(nn);
+        float hx = nx * inv, hy = ny * inv, hz = nz * inv;
+        L = (hx * f.lx + hy * f.ly) + hz * f.lz;
+        if (!(L > 0.0f)) L = 0.0f;
+    }
+    return L;
+}
+
+// fragmentShader + interpolated vertex colour (src/shader.slang:27, 31-36), optional Lambert term `L`
+// (lambert_term of the same triangle).  A, B, C are the winning triangle's records.
+__device__ __forceinline__ void shade_hit_with(const FrameK& f, const Hit& h, const float4& A, const float4& B,
+                                               const float4& C, float L, float& r, float& g, float& b) {
     float u = h.un / h.det, v = h.vn / h.det;
     float w0 = (1.0f - u) - v;
     float c0 = A.z * 10.0f, c1 = B.w * 10.0f, c2 = C.w * 10.0f;
     float cb = (w0 * c0 + u * c1) + v * c2;
     r = 1.0f, g = 1.0f, b = cb;
-    if (f.flags & INV_LAMBERT) {
-        float nx = B.y * C.z - B.z * C.y;
-        float ny = B.z * C.x - B.x * C.z;
-        float nz = B.x * C.y - B.y * C.x;
-        float nn = (nx * nx + ny * ny) + nz * nz;
-        float L = 0.0f;
-        if (nn > 0.0f) {
-            float inv = 1.0f / sqrtf(nn);
-            float hx = nx * inv, hy = ny * inv, hz = nz * inv;
-            L = (hx * f.lx + hy * f.ly) + hz * f.lz;
-            if (!(L > 0.0f)) L = 0.0f;
-        }
-        r = r * L, g = g * L, b = b * L;
-    }
+    if (f.flags & INV_LAMBERT) r = r * L, g = g * L, b = b * L;
+}
+
+__device__ __forceinline__ void shade_hit(const FrameK& f, const Hit& h, const float4& A, const float4& B,
+                                          const float4& C, float& r, float& g, float& b) {
+    shade_hit_with(f, h, A, B, C, (f.flags & INV_LAMBERT) ? lambert_term(f, B, C) : 1.0f, r, g, b);
 }
 
 __device__ __forceinline__ void shade_sample(const FrameK& f, const Hit& h, const float4* __restrict__ TA,

@@ -493,6 +493,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                     S.u.t.rec[at][2] = C;
                     float4 P0, P1, P2;
                     fold_triangle(f.ox, f.oy, f.oz, dabs, A, B, C, P0, P1, P2);
+                    if (f.flags & INV_LAMBERT) P1.w = lambert_term(f, B, C); // once per record, not per shaded sample
                     S.u.t.pre[at][0] = P0;
                     S.u.t.pre[at][1] = P1;
                     S.u.t.pre[at][2] = P2;
@@ -557,7 +558,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
             }
             float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
             if (best.key != kMissKey)
-                shade_hit(f, best, S.u.t.rec[best.slot][0], S.u.t.rec[best.slot][1], S.u.t.rec[best.slot][2], r, g, b);
+                shade_hit_with(f, best, S.u.t.rec[best.slot][0], S.u.t.rec[best.slot][1], S.u.t.rec[best.slot][2],
+                               S.u.t.pre[best.slot][1].w, r, g, b);
             S.win[wave * 64u + lane] = make_float4(r, g, b, 0.0f);
             if (s == 0) first = best; // sample 0 is the first wave's
         }
@@ -614,7 +616,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                 if (batched)
                     shade_hit(f, h, TA[h.slot], TB[h.slot], TC[h.slot], r, g, b);
                 else
-                    shade_hit(f, h, S.u.t.rec[h.slot][0], S.u.t.rec[h.slot][1], S.u.t.rec[h.slot][2], r, g, b);
+                    shade_hit_with(f, h, S.u.t.rec[h.slot][0], S.u.t.rec[h.slot][1], S.u.t.rec[h.slot][2],
+                                   S.u.t.pre[h.slot][1].w, r, g, b);
                 if (s == 0) first = h;
             }
             sr = sr + r, sg = sg + g, sb = sb + b;
