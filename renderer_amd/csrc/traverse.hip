@@ -493,7 +493,9 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW>& S, uint
                     S.u.t.rec[at][2] = C;
                     float4 P0, P1, P2;
                     fold_triangle(f.ox, f.oy, f.oz, dabs, A, B, C, P0, P1, P2);
-                    if (f.flags & INV_LAMBERT) P1.w = lambert_term(f, B, C); // once per record, not per shaded sample
+                    // once per record instead of once per shaded sample (the batched variant shades from the
+                    // triangle arrays and would not use it)
+                    if (!BATCHED && (f.flags & INV_LAMBERT)) P1.w = lambert_term(f, B, C);
                     S.u.t.pre[at][0] = P0;
                     S.u.t.pre[at][1] = P1;
                     S.u.t.pre[at][2] = P2;
