@@ -36,6 +36,9 @@ import renderer_amd as R  # noqa: E402
 from renderer_amd import dist as RD  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+VALU_PEAK_TFLOPS = 157.3  # fp32 vector: 256 CUs x 4 SIMDs x 16 lanes x 2 flops (FMA) x 2.4 GHz
+# algorithmic flops of the per-ray steps (counted on the CPU oracle's own traversal, not on the GPU)
+FLOPS_RAY, FLOPS_BOX, FLOPS_TRI, FLOPS_SHADE = 20, 22, 51, 15
 
 WORKLOADS = {
     # the configuration the headline metric is quoted on
@@ -78,7 +81,8 @@ def cpu_baseline(wl, budget_s=8.0):
     cam = O.camera_reference(w, h)
     prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"], ao_rays=wl.get("ao_rays", 0))
     cores = min(16, os.cpu_count() or 1)
-    O.render_bvh(xyzw, idx, cam, prm, nthreads=cores)  # warm
+    cnt = O.Counters()
+    O.render_bvh(xyzw, idx, cam, prm, nthreads=cores, counters=cnt)  # warm; also counts the traversal's tests
     frames, t0 = 0, time.perf_counter()
     while True:
         out = O.render_bvh(xyzw, idx, cam, prm, nthreads=cores)
@@ -88,9 +92,11 @@ def cpu_baseline(wl, budget_s=8.0):
             break
     hits = int((out[2] != 0xFFFFFFFF).sum())
     rays = (w * h * wl["spp"] + wl.get("ao_rays", 0) * hits) * frames
+    flops = (FLOPS_RAY * cnt.rays + FLOPS_BOX * cnt.box_tests + FLOPS_TRI * cnt.tri_tests + FLOPS_SHADE * cnt.hits)
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
                 sample="%d whole %dx%d frames (%d spp) through the oracle's CPU LBVH, %d threads, %.1f s"
-                       % (frames, w, h, wl["spp"], cores, dt)), out
+                       % (frames, w, h, wl["spp"], cores, dt)), out, dict(
+        rays=int(cnt.rays), box_tests=int(cnt.box_tests), tri_tests=int(cnt.tri_tests), hits=int(cnt.hits), flops=int(flops))
 
 
 def main():
@@ -249,6 +255,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "mesh": "bunny (2503 v / 4968 f, regenerated from the fixture)",
                        "width": w, "height": h, "spp": spp, "ao_rays": ao_rays, "hit_pixels": hit_pixels,
+                       # 98.8 % of the primary rays miss the scene's bounds: the rate over rays of hit pixels only
+                       "hit_pixel_mrays_per_s": (hit_pixels * spp + ao_rays * hit_pixels) * args.steps / elapsed / 1e6,
                        "rays_per_frame": rays_per_step, "flags": int(flags),
                        "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0" % (args.composite, world)
@@ -260,7 +268,7 @@ def main():
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            base, oracle_out = cpu_baseline(wl)
+            base, oracle_out, work = cpu_baseline(wl)
             # outputs are compared before the timing is accepted
             got = planes.cpu().numpy()
             ok = (np.array_equal(got[2].view(np.uint32).reshape(h, w), oracle_out[2])
@@ -270,6 +278,11 @@ def main():
                 raise SystemExit("GPU output differs from the CPU oracle: timing rejected")
             base["outputs_match_gpu"] = True
             result["cpu_baseline"] = base
+            # VALU side of the roofline: flops of a per-ray LBVH traversal of this frame (the oracle's test counts;
+            # the tile kernel does fewer box tests than that) over the measured kernel time
+            tflops = work["flops"] / (kernel_ms * 1e-3) / 1e12
+            result["roofline"]["valu"] = {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": tflops / VALU_PEAK_TFLOPS, "oracle_traversal": work}
         print(json.dumps(result))
     scene.close()
     ctx.close()
