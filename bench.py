@@ -47,6 +47,9 @@ WORKLOADS = {
     "bunny_4k_16spp": dict(width=3840, height=2160, spp=16, flags=R.LAMBERT | R.INVERT),
     # 64 occlusion rays per hit pixel on top of the headline configuration
     "bunny_1080p_ao64": dict(width=1920, height=1080, spp=1, ao_rays=64, flags=R.LAMBERT | R.INVERT),
+    # the model turning at 90 degrees per second, one frame per 1/60 s: a stream of different frames from one scene
+    # build (one GPU only)
+    "bunny_1080p_turntable": dict(width=1920, height=1080, spp=1, flags=R.LAMBERT | R.INVERT, turntable=True),
     # the headline extent in parity mode (what the reference's shaders draw: no Lambert, no invert)
     "bunny_1080p_parity": dict(width=1920, height=1080, spp=1, flags=0),
 }
@@ -72,13 +75,13 @@ def pmc_traffic(workload, world):
     return best
 
 
-def cpu_baseline(wl, budget_s=8.0):
+def cpu_baseline(wl, budget_s=8.0, elapsed_s=None):
     """Time the CPU oracle on the same frame (bounded: whole frames until the budget is used)."""
     from oracle import oracle as O
 
     xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
     w, h = wl["width"], wl["height"]
-    cam = O.camera_reference(w, h)
+    cam = O.camera_reference(w, h) if elapsed_s is None else O.camera_turntable(w, h, elapsed_s)
     prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"], ao_rays=wl.get("ao_rays", 0))
     cores = min(16, os.cpu_count() or 1)
     cnt = O.Counters()
@@ -145,6 +148,10 @@ def main():
     scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))  # every rank holds the whole scene
     ntri, nnodes, scene_bytes = scene.counts()
     cam = R.camera_reference(w, h)
+    turntable = bool(wl.get("turntable"))
+    if turntable and world > 1:
+        raise SystemExit("the turntable workload runs on one GPU")
+    cams = [R.camera_turntable(w, h, i / 60.0) for i in range(240)] if turntable else None  # one full turn
     ao_rays = wl.get("ao_rays", 0)
     sparse = world > 1 and args.composite == "sparse"
     gathered = frame = sc = None
@@ -181,7 +188,7 @@ def main():
         if sparse:
             sc.render()
         else:
-            scene.render_device(cam, prm, ptr[0], ptr[1], ptr[2])
+            scene.render_device(cams[(i or 0) % len(cams)] if turntable else cam, prm, ptr[0], ptr[1], ptr[2])
         if timed:
             ev1[i // every].record(stream)
         if sparse:
@@ -268,7 +275,9 @@ def main():
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            base, oracle_out, work = cpu_baseline(wl)
+            # (turntable: the frame left in the buffers is the last step's)
+            base, oracle_out, work = cpu_baseline(
+                wl, elapsed_s=((args.steps - 1) % len(cams)) / 60.0 if turntable else None)
             # outputs are compared before the timing is accepted
             got = planes.cpu().numpy()
             ok = (np.array_equal(got[2].view(np.uint32).reshape(h, w), oracle_out[2])

@@ -107,6 +107,10 @@ int inv_mesh_destroy(inv_mesh* mesh);                   /* Obj::~Obj (src/invert
 /* The camera the reference hard-codes (src/invert.cpp:630-639): eye (0,0,1) looking at the origin, a 180 degree
  * roll, 45 degree vertical field of view, near 0.1, far 10, aspect width/height, zero-to-one depth. */
 int inv_camera_reference(uint32_t width, uint32_t height, inv_camera* cam);
+/* The same camera with the model matrix turned about the up axis by elapsed_seconds * 90 degrees: a use for the
+ * `elapsed` the reference measures every frame and ignores (src/invert.cpp:623-626).  The scene's LBVH is built in
+ * object space, so a sequence of such frames (or of any cameras and extents) reuses it unchanged. */
+int inv_camera_turntable(uint32_t width, uint32_t height, float elapsed_seconds, inv_camera* cam);
 
 /* ---- scene: vertex/index buffers + acceleration structure -------------------------------------------------- */
 /* Uploads the mesh (src/invert.cpp:1136-1140, 1161-1164), assembles triangle k from indices 3k..3k+2

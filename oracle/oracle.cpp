@@ -857,6 +857,14 @@ void orc_camera_reference(uint32_t width, uint32_t height, orc_camera* cam) {
     glm_perspective_rh_zo(glm_radians(45.0f), (float)width / (float)height, 0.1f, 10.0f, cam->proj); // :639
 }
 
+// Turntable: the reference camera with model = rotate(identity, elapsed * radians(90), up) -- a use for the
+// `elapsed` that src/invert.cpp:623-626 measures and ignores.
+void orc_camera_turntable(uint32_t width, uint32_t height, float elapsed_seconds, orc_camera* cam) {
+    orc_camera_reference(width, height, cam);
+    mat_identity(cam->model);
+    glm_rotate(cam->model, elapsed_seconds * glm_radians(90.0f), V3{0.0f, 1.0f, 0.0f});
+}
+
 void orc_vertex_shader(const float* xyzw, uint32_t nv, const orc_camera* cam, float* clip4, float* color3) {
     for (uint32_t i = 0; i < nv; i++) {
         float p[4] = {xyzw[(size_t)i * 4], xyzw[(size_t)i * 4 + 1], xyzw[(size_t)i * 4 + 2], 1.0f};

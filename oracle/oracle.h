@@ -67,6 +67,7 @@ void orc_free(void* p);
 
 /* A2: src/invert.cpp:621-642. */
 void orc_camera_reference(uint32_t width, uint32_t height, orc_camera* cam);
+void orc_camera_turntable(uint32_t width, uint32_t height, float elapsed_seconds, orc_camera* cam);
 
 /* A3: src/shader.slang:22-29.  clip = P*(V*(M*(pos,1))), colour = (1,1,10*z). */
 void orc_vertex_shader(const float* xyzw, uint32_t nv, const orc_camera* cam, float* clip4, float* color3);

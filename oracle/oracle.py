@@ -54,6 +54,8 @@ def lib():
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_camera_reference.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera)]
         L.orc_camera_reference.restype = None
+        L.orc_camera_turntable.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(Camera)]
+        L.orc_camera_turntable.restype = None
         L.orc_vertex_shader.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Camera), C.c_void_p, C.c_void_p]
         L.orc_vertex_shader.restype = None
         L.orc_frame_setup.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Camera), C.c_void_p]
@@ -107,6 +109,12 @@ def parse_obj(data: bytes):
 def camera_reference(w: int, h: int) -> Camera:
     cam = Camera()
     lib().orc_camera_reference(w, h, C.byref(cam))
+    return cam
+
+
+def camera_turntable(w: int, h: int, elapsed_seconds: float) -> Camera:
+    cam = Camera()
+    lib().orc_camera_turntable(w, h, elapsed_seconds, C.byref(cam))
     return cam
 
 

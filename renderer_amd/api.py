@@ -23,7 +23,7 @@ SYMBOLS = (
     "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize",
     "inv_mesh_load_obj", "inv_mesh_load_obj_general", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
     "inv_mesh_indices", "inv_mesh_destroy",
-    "inv_camera_reference",
+    "inv_camera_reference", "inv_camera_turntable",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
     "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
     "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
@@ -89,6 +89,7 @@ def lib():
     L.inv_mesh_indices.restype = u32p
     L.inv_mesh_destroy.argtypes = [vp]
     L.inv_camera_reference.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera)]
+    L.inv_camera_turntable.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(Camera)]
     L.inv_scene_build.argtypes = [vp, vp, C.POINTER(vp)]
     L.inv_scene_build_instanced.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(vp)]
     L.inv_scene_counts.argtypes = [vp, u32p, u32p, u64p]
@@ -124,6 +125,13 @@ def camera_reference(width: int, height: int) -> Camera:
     """The reference's hard-coded camera (src/invert.cpp:630-639)."""
     cam = Camera()
     _chk(lib().inv_camera_reference(width, height, C.byref(cam)))
+    return cam
+
+
+def camera_turntable(width: int, height: int, elapsed_seconds: float) -> Camera:
+    """The reference camera with the model turned about the up axis by elapsed_seconds * 90 degrees."""
+    cam = Camera()
+    _chk(lib().inv_camera_turntable(width, height, elapsed_seconds, C.byref(cam)))
     return cam
 
 

@@ -136,6 +136,15 @@ void reference_camera(uint32_t width, uint32_t height, inv_camera* cam) {
     perspective_rh_zo(to_radians(45.0f), (float)width / (float)height, 0.1f, 10.0f).store(cam->proj); // :639
 }
 
+// The reference measures `elapsed` every frame and never uses it (src/invert.cpp:623-626).  This is the use the
+// structure invites: the model matrix turns about the up axis at 90 degrees per second, everything else as in
+// reference_camera.  elapsed = 0 gives exactly the reference camera (rotate by 0 is the identity matrix).
+void turntable_camera(uint32_t width, uint32_t height, float elapsed_seconds, inv_camera* cam) {
+    reference_camera(width, height, cam);
+    const float angle = elapsed_seconds * to_radians(90.0f);
+    rotate(Mat4::identity(), angle, {0.0f, 1.0f, 0.0f}).store(cam->model);
+}
+
 int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f) {
     const Mat4 P = Mat4::load(cam.proj);
     // Rays are generated from the diagonal terms only, so the projection must have GLM's perspective shape.

@@ -264,6 +264,14 @@ int inv_camera_reference(uint32_t width, uint32_t height, inv_camera* cam) {
     return INV_OK;
 }
 
+int inv_camera_turntable(uint32_t width, uint32_t height, float elapsed_seconds, inv_camera* cam) {
+    if (!cam) return fail(INV_ERR_ARG, "inv_camera_turntable: cam is null");
+    if (width == 0 || height == 0) return fail(INV_ERR_ARG, "inv_camera_turntable: zero extent");
+    if (!std::isfinite(elapsed_seconds)) return fail(INV_ERR_ARG, "inv_camera_turntable: elapsed_seconds is not finite");
+    turntable_camera(width, height, elapsed_seconds, cam);
+    return INV_OK;
+}
+
 // ---- scene ---------------------------------------------------------------------------------------
 int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* translations_xyz, uint32_t ninst,
                               inv_scene** out) try {

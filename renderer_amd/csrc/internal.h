@@ -27,6 +27,7 @@ int write_primid(const char* path, const uint32_t* primid, uint32_t w, uint32_t 
 
 // A2 -- camera.cpp
 void reference_camera(uint32_t width, uint32_t height, inv_camera* cam);
+void turntable_camera(uint32_t width, uint32_t height, float elapsed_seconds, inv_camera* cam);
 // view*model, its inverse (double Gauss-Jordan rounded to float) and the Lambert light direction.
 int frame_from_camera(const inv_camera& cam, float max_abs_coord, FrameK* f);
 // Pixel rectangle [x0, x1) x [y0, y1) outside which no ray can hit anything inside `bbox`.

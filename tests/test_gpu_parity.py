@@ -231,6 +231,18 @@ def test_sparse_composite_with_nothing_on_screen(bunny_scene, gpu_ctx):
     common.assert_frames_equal(got, full, "empty sparse composite")
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_turntable_frames_reuse_the_scene(oracle, bunny_scene, bunny_mesh, mode):
+    """A sequence of frames with the model turning and the extent changing, all from one scene build: rays are cast
+    in object space, so neither the triangles nor the LBVH depend on the camera."""
+    for t, (w, h) in ((0.3, (1920, 1080)), (1.0, (640, 360)), (2.5, (1280, 720)), (3.75, (1920, 1080))):
+        prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT | mode)
+        got = bunny_scene.render(R.camera_turntable(w, h, t), prm)
+        want = oracle.render_bvh(*bunny_mesh, oracle.camera_turntable(w, h, t), _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "t=%.2f %dx%d" % (t, w, h))
+        assert (got[2] != 0xFFFFFFFF).sum() > 2000
+
+
 def test_device_outputs_on_torch_stream(bunny_scene, bunny_path):
     """Device-pointer outputs on the caller's stream (the path bench.py times)."""
     import torch

@@ -121,6 +121,20 @@ def test_camera_pins():
         R.camera_reference(0, 10)
 
 
+def test_turntable_camera(oracle):
+    """elapsed * 90 degrees about the up axis on the model matrix; bit-identical to the oracle's; elapsed = 0 is the
+    reference camera; one second is a quarter turn (x -> -z)."""
+    for t in (0.0, 0.3, 1.0, 2.5, -7.25, 1234.5):
+        assert bytes(R.camera_turntable(1920, 1080, t)) == bytes(oracle.camera_turntable(1920, 1080, t))
+    ref, zero = R.camera_reference(640, 480), R.camera_turntable(640, 480, 0.0)
+    assert np.array_equal(np.array(zero.model, np.float32), np.array(ref.model, np.float32))
+    assert bytes(zero)[64:] == bytes(ref)[64:]  # view, projection and camera angle are untouched
+    m = np.array(R.camera_turntable(640, 480, 1.0).model, np.float32).reshape(4, 4).T  # column-major storage
+    assert np.allclose(m @ np.array([1, 0, 0, 1], np.float32), [0, 0, -1, 1], atol=1e-6)
+    with pytest.raises(R.InvertError):
+        R.camera_turntable(640, 480, float("nan"))
+
+
 def test_tile_layout():
     prm = R.make_params(1920, 1080)
     npix, ids = R.tile_layout(prm)
