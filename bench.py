@@ -47,6 +47,10 @@ WORKLOADS = {
     "bunny_4k_16spp": dict(width=3840, height=2160, spp=16, flags=R.LAMBERT | R.INVERT),
     # 64 occlusion rays per hit pixel on top of the headline configuration
     "bunny_1080p_ao64": dict(width=1920, height=1080, spp=1, ao_rays=64, flags=R.LAMBERT | R.INVERT),
+    # the same from close by (eye 0.3 from the model instead of 1): the bunny fills the frame, so the occlusion rays
+    # (64 per hit pixel) are most of the work
+    "bunny_1080p_ao64_closeup": dict(width=1920, height=1080, spp=1, ao_rays=64, flags=R.LAMBERT | R.INVERT,
+                                     view_translation=(0.0, 0.11, -0.3)),
     # the model turning at 90 degrees per second, one frame per 1/60 s: a stream of different frames from one scene
     # build (one GPU only)
     "bunny_1080p_turntable": dict(width=1920, height=1080, spp=1, flags=R.LAMBERT | R.INVERT, turntable=True),
@@ -75,13 +79,13 @@ def pmc_traffic(workload, world):
     return best
 
 
-def cpu_baseline(wl, budget_s=8.0, elapsed_s=None):
+def cpu_baseline(wl, camera, budget_s=8.0):
     """Time the CPU oracle on the same frame (bounded: whole frames until the budget is used)."""
     from oracle import oracle as O
 
     xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
     w, h = wl["width"], wl["height"]
-    cam = O.camera_reference(w, h) if elapsed_s is None else O.camera_turntable(w, h, elapsed_s)
+    cam = O.Camera.from_buffer_copy(bytes(camera))  # the same 204 bytes the GPU drew with
     prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"], ao_rays=wl.get("ao_rays", 0))
     cores = min(16, os.cpu_count() or 1)
     cnt = O.Counters()
@@ -148,6 +152,8 @@ def main():
     scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))  # every rank holds the whole scene
     ntri, nnodes, scene_bytes = scene.counts()
     cam = R.camera_reference(w, h)
+    if "view_translation" in wl:  # the reference camera moved: same roll and lens, another eye position
+        cam.view[12], cam.view[13], cam.view[14] = wl["view_translation"]
     turntable = bool(wl.get("turntable"))
     if turntable and world > 1:
         raise SystemExit("the turntable workload runs on one GPU")
@@ -276,8 +282,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
-            base, oracle_out, work = cpu_baseline(
-                wl, elapsed_s=((args.steps - 1) % len(cams)) / 60.0 if turntable else None)
+            base, oracle_out, work = cpu_baseline(wl, cams[(args.steps - 1) % len(cams)] if turntable else cam)
             # outputs are compared before the timing is accepted
             got = planes.cpu().numpy()
             ok = (np.array_equal(got[2].view(np.uint32).reshape(h, w), oracle_out[2])
