@@ -4,7 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 One step = one frame of the workload rendered through the C ABI (include/invert.h) with every input
-(triangles, LBVH) and output buffer resident in HBM.  With N > 1 (launched by torch.distributed.run, one
+(triangles, LBVH) and output buffer resident in HBM.  On one GPU the frames go round-robin to --frames-in-flight
+frame slots (default 2, the reference's MAX_FRAMES_IN_FLIGHT, src/invert.cpp:241): every frame is a whole draw into
+its slot's own attachments, and draws on different slots overlap on the GPU.  With N > 1 (launched by torch.distributed.run, one
 process per GPU) 32x32 screen tiles are dealt round-robin to the ranks, every rank renders its tiles, and the
 three attachments are gathered to rank 0 over RCCL and put together there; the same frame is rendered whatever N
 is, so scaling is "strong".  --composite sparse (default) deals out only the tiles under the scene's projected
@@ -112,6 +114,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
+                    help="one GPU: frame slots the frames are dealt to (1 = every draw on the context's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
     ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
@@ -161,6 +165,7 @@ def main():
     ao_rays = wl.get("ao_rays", 0)
     sparse = world > 1 and args.composite == "sparse"
     gathered = frame = sc = None
+    fif = args.frames_in_flight if world == 1 else 1  # the composite of several ranks runs on the context's stream
     if sparse:
         sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=flags, ao_rays=ao_rays)
         frame, gathered = sc.frame, sc.gathered
@@ -170,24 +175,35 @@ def main():
         prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
         npix, _ = R.tile_layout(prm)
         # one buffer, three planes (colour, depth, primitive id), 4 bytes per pixel each
-        planes = torch.empty(3, npix, dtype=torch.int32, device="cuda")
-        ptr = [planes[i].data_ptr() for i in range(3)]
+        slot_planes = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif)]
+        slot_ptr = [[p[i].data_ptr() for i in range(3)] for p in slot_planes]
+        planes, ptr = slot_planes[0], slot_ptr[0]
         if world > 1 and rank == 0:
             gathered = torch.empty(world, 3, npix, dtype=torch.int32, device="cuda")
             frame = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
         prm0 = R.make_params(w, h, tile=tile, nranks=world)
 
-    # Render-kernel duration: with one GPU two HIP events bracket the K launches of the timed region (the stream
-    # holds nothing else, so their distance / K is the average launch-to-launch time of the kernel; a pair of
-    # events around every launch would add about 3 us of marker latency to a 13 us kernel).  With several GPUs
-    # the stream also carries the gather, so there a pair of events brackets every 4th render launch.
+    # Render-kernel duration: with one GPU two HIP events per stream bracket that stream's launches of the timed
+    # region (a stream holds nothing else, so their distance / launches is the average launch-to-launch time of
+    # the kernel on it; a pair of events around every launch would add about 3 us of marker latency to a 13 us
+    # kernel).  With several frames in flight that is the duration of a kernel that shares the GPU with the other
+    # slots' kernels; the frame rate is `fif` times higher.  With several GPUs the stream also carries the gather,
+    # so there a pair of events brackets every 4th render launch.
     every = 4
     nev = (args.steps + every - 1) // every
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    slot_streams = slot_ev = None
+    if fif > 1:
+        slot_streams = [torch.cuda.ExternalStream(ctx.frame_stream(j)) for j in range(fif)]
+        slot_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(fif)]
 
     def step(i=None):
+        if fif > 1:
+            j = (i or 0) % fif
+            scene.render_in_flight(j, cams[(i or 0) % len(cams)] if turntable else cam, prm, *slot_ptr[j])
+            return
         timed = world > 1 and i is not None and i % every == 0
         if timed:
             ev0[i // every].record(stream)
@@ -217,16 +233,23 @@ def main():
             if rank == 0:
                 RD.deinterleave_on_gpu(ctx, prm0, gathered, frame)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i if fif > 1 else None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev_begin.record(stream)
+    if fif > 1:
+        for j in range(fif):
+            slot_ev[j][0].record(slot_streams[j])
     for i in range(args.steps):
         step(i)
+    if fif > 1:
+        for j in range(fif):
+            slot_ev[j][1].record(slot_streams[j])
+        ctx.frames_join()  # the context's stream (and ev_end on it) waits for every slot
     ev_end.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -235,8 +258,22 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nev
+    elif fif > 1:
+        spans = [(slot_ev[j][0].elapsed_time(slot_ev[j][1]), len(range(j, args.steps, fif))) for j in range(fif)]
+        kernel_ms = sum(sp for sp, n in spans if n) / max(1, sum(n for sp, n in spans))
     else:
         kernel_ms = ev_begin.elapsed_time(ev_end) / args.steps
+
+    alone_ms = None
+    if fif > 1:
+        # after the timed region: the same launches on one slot only, i.e. the kernel with the GPU to itself
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(slot_streams[0])
+        for i in range(args.steps):
+            scene.render_in_flight(0, cams[i % len(cams)] if turntable else cam, prm, *slot_ptr[(args.steps - 1) % fif])
+        a1.record(slot_streams[0])
+        torch.cuda.synchronize()
+        alone_ms = a0.elapsed_time(a1) / args.steps
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -252,6 +289,10 @@ def main():
         if not torch.equal(alone, frame):
             raise SystemExit("composited frame differs from the single-GPU frame: timing rejected")
 
+    if world == 1:
+        planes = slot_planes[(args.steps - 1) % fif]  # the attachments of the last frame
+        if not turntable and not all(torch.equal(planes, p) for p in slot_planes[:min(fif, args.steps + args.warmup)]):
+            raise SystemExit("the frame slots hold different frames: timing rejected")
     if rank == 0:
         final = frame if world > 1 else planes
         hit_pixels = int((final[2] != -1).sum()) if world == 1 or rank == 0 else 0
@@ -271,15 +312,21 @@ def main():
                        # 98.8 % of the primary rays miss the scene's bounds: the rate over rays of hit pixels only
                        "hit_pixel_mrays_per_s": (hit_pixels * spp + ao_rays * hit_pixels) * args.steps / elapsed / 1e6,
                        "rays_per_frame": rays_per_step, "flags": int(flags),
-                       "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile,
+                       "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile, "frames_in_flight": fif,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0" % (args.composite, world)
                                        if world > 1 else "1 GPU")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
                          "kernel": ("k_render_brute" if args.brute_force else "k_render_tile") + ("+k_ao" if ao_rays else ""),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                         # the same bytes over the frame time of the whole job (kernels of different slots overlap)
+                         "job": {"achieved": alg_bytes * args.steps / elapsed / 1e9,
+                                 "frac": alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}},
             "cpu_baseline": None,
         }
+        if alone_ms is not None:  # the same kernel when no other slot's kernel shares the GPU with it
+            result["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": alg_bytes / (alone_ms * 1e-3) / 1e9,
+                                           "frac": alg_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
             base, oracle_out, work = cpu_baseline(wl, cams[(args.steps - 1) % len(cams)] if turntable else cam)

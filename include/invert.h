@@ -139,6 +139,31 @@ int inv_vertex_shader(inv_scene* scene, const inv_camera* cam, float* clip4, flo
  * src/invert.cpp:1331-1337, 1380-1385), its depth and its colour (src/shader.slang:27, 31-36) stored as sRGB8. */
 int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out);
 
+/* ---- frames in flight ------------------------------------------------------------------------------------------ */
+/* The reference keeps MAX_FRAMES_IN_FLIGHT = 2 frames in flight (src/invert.cpp:241): drawFrame waits for the fence
+ * of the frame slot it is about to reuse (src/invert.cpp:646), records and submits that slot's command buffer with
+ * the fence (src/invert.cpp:655-672), moves on to the next slot (src/invert.cpp:698) and so returns while the GPU
+ * still draws.  Here a frame slot is a HIP stream of the context's own plus whatever the draw needs beside the
+ * caller's attachments (host staging, the occlusion queue), so draws enqueued on different slots run on the GPU
+ * at the same time: the dispatch gap and the tail of one frame's slowest tiles are filled by the next frame.
+ *
+ * inv_render_in_flight is inv_render on slot `slot` (< INV_MAX_FRAMES_IN_FLIGHT) instead of the context's stream.
+ * Slots are independent of each other and of the context's stream: give every slot attachments of its own, and
+ * before anything else touches a slot's attachments either wait on the host (inv_frame_wait) or order the context's
+ * stream after the slots (inv_frames_join).  Streams are created on first use and live as long as the context. */
+#define INV_MAX_FRAMES_IN_FLIGHT 4
+int inv_render_in_flight(inv_scene* scene, uint32_t slot, const inv_camera* cam, const inv_params* params,
+                         const inv_outputs* out);
+/* vkWaitForFences on the slot's fence (src/invert.cpp:646): blocks the host until every draw enqueued on the slot
+ * has finished.  A slot that was never used returns at once. */
+int inv_frame_wait(inv_ctx* ctx, uint32_t slot);
+/* Device-side join: work enqueued on the context's stream after this call starts only when everything enqueued on
+ * the slots so far has finished (the host does not wait).  The counterpart of the semaphore the reference's submit
+ * signals for its present (src/invert.cpp:660-683). */
+int inv_frames_join(inv_ctx* ctx);
+/* The slot's hipStream_t, for callers that record their own events on it or order their own streams after it. */
+int inv_frame_stream(inv_ctx* ctx, uint32_t slot, void** hip_stream);
+
 /* Number of pixels rank `rank` owns and, optionally, the tile ids in the order they are stored. */
 int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_ids, uint32_t tile_ids_cap,
                     uint32_t* ntiles);

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INVERT_HIP_LIB") or os.path.join(_HERE, "libinvert_hip.so")
 
 LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL, SPARSE = 1, 2, 4, 8, 16, 32
+MAX_FRAMES_IN_FLIGHT = 4  # INV_MAX_FRAMES_IN_FLIGHT
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(8)
 
 # every symbol include/invert.h declares
@@ -26,6 +27,7 @@ SYMBOLS = (
     "inv_camera_reference", "inv_camera_turntable",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
     "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
+    "inv_render_in_flight", "inv_frame_wait", "inv_frames_join", "inv_frame_stream",
     "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
     "inv_write_ppm", "inv_write_pfm", "inv_write_primid",
     "inv_last_error", "inv_version",
@@ -97,6 +99,10 @@ def lib():
     L.inv_scene_read_lbvh.argtypes = [vp] + [vp] * 6
     L.inv_vertex_shader.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int]
     L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
+    L.inv_render_in_flight.argtypes = [vp, C.c_uint32, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
+    L.inv_frame_wait.argtypes = [vp, C.c_uint32]
+    L.inv_frames_join.argtypes = [vp]
+    L.inv_frame_stream.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     L.inv_tile_layout.argtypes = [C.POINTER(Params), u64p, u32p, C.c_uint32, u32p]
     L.inv_deinterleave.argtypes = [vp, C.POINTER(Params), vp, C.c_uint64, vp, C.c_uint32]
     rect = C.POINTER(C.c_uint32 * 4)
@@ -229,6 +235,20 @@ class Context:
     def synchronize(self):
         _chk(lib().inv_ctx_synchronize(self._h))
 
+    def frame_wait(self, slot: int):
+        """Block until every draw enqueued on frame slot `slot` has finished (the reference's fence wait)."""
+        _chk(lib().inv_frame_wait(self._h, slot))
+
+    def frames_join(self):
+        """Order the context's stream after everything enqueued on the frame slots so far (no host wait)."""
+        _chk(lib().inv_frames_join(self._h))
+
+    def frame_stream(self, slot: int) -> int:
+        """hipStream_t handle of frame slot `slot` (created on first use)."""
+        s = C.c_void_p()
+        _chk(lib().inv_frame_stream(self._h, slot, C.byref(s)))
+        return s.value or 0
+
     def deinterleave(self, prm: Params, gathered_ptr: int, frame_ptr: int, rank_stride: int = 0):
         _chk(lib().inv_deinterleave(self._h, C.byref(prm), C.c_void_p(gathered_ptr), rank_stride,
                                     C.c_void_p(frame_ptr), 4))
@@ -340,6 +360,27 @@ class Scene:
         rc = lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(self._dev_out))
         if rc:
             _chk(rc)
+
+    def render_in_flight(self, slot: int, cam: Camera, prm: Params, color_ptr: int = 0, depth_ptr: int = 0,
+                         primid_ptr: int = 0):
+        """Enqueue the draw into device buffers on frame slot `slot` (a stream of its own): draws on different slots
+        overlap on the GPU.  Context.frame_wait / frames_join order the consumers."""
+        cache = self.__dict__.setdefault("_flight_out", {})
+        key = (slot, color_ptr, depth_ptr, primid_ptr)
+        out = cache.get(key)
+        if out is None:
+            out = cache[key] = Outputs(color_ptr or None, depth_ptr or None, primid_ptr or None, 1)
+        rc = lib().inv_render_in_flight(self._h, slot, C.byref(cam), C.byref(prm), C.byref(out))
+        if rc:
+            _chk(rc)
+
+    def render_in_flight_host(self, slot: int, cam: Camera, prm: Params):
+        """inv_render_in_flight into host arrays (the call waits for that slot): (colour, depth, primid) of a whole frame."""
+        h, w = prm.height, prm.width
+        color, depth, primid = np.empty((h, w, 4), np.uint8), np.empty((h, w), np.float32), np.empty((h, w), np.uint32)
+        out = Outputs(color.ctypes.data, depth.ctypes.data, primid.ctypes.data, 0)
+        _chk(lib().inv_render_in_flight(self._h, slot, C.byref(cam), C.byref(prm), C.byref(out)))
+        return color, depth, primid
 
     def close(self):
         if self._h:

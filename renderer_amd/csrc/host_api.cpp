@@ -43,6 +43,9 @@ struct inv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // frame slots (created on first use): a stream each, and an event the join records on it
+    hipStream_t flight[INV_MAX_FRAMES_IN_FLIGHT] = {};
+    hipEvent_t flight_done[INV_MAX_FRAMES_IN_FLIGHT] = {};
 };
 
 struct inv_mesh {
@@ -50,18 +53,25 @@ struct inv_mesh {
     std::vector<uint32_t> idx;
 };
 
+// What one draw needs beside the caller's attachments.  Draws on different streams must not share it, so a scene
+// holds one for the context's stream and one per frame slot.
+struct FrameScratch {
+    // device staging for host-pointer outputs (grow-only)
+    void* stage[3] = {nullptr, nullptr, nullptr};
+    uint64_t stage_elems = 0;
+    float* ao_queue = nullptr; // occlusion-pass queue (grow-only): 256-byte header with the counter, then records
+    uint64_t ao_cap = 0;
+};
+
 struct inv_scene {
     inv_ctx* ctx = nullptr;
     DeviceScene d;
     float max_abs = 0.0f;
-    // device staging for host-pointer outputs (grow-only)
-    void* stage[3] = {nullptr, nullptr, nullptr};
-    uint64_t stage_elems = 0;
     float* vs_stage = nullptr;
     uint64_t vs_stage_floats = 0;
     float vertex_diag = 0.0f; // diagonal of the vertices' bounding box: default reach of occlusion rays
-    float* ao_queue = nullptr; // occlusion-pass queue (grow-only): 256-byte header with the counter, then records
-    uint64_t ao_cap = 0;
+    FrameScratch main;                             // draws on the context's stream
+    FrameScratch flight[INV_MAX_FRAMES_IN_FLIGHT]; // draws on the frame slots
 };
 
 namespace {
@@ -76,6 +86,13 @@ void free_device_scene(DeviceScene& d) {
     dfree(d.arena); // every array of the scene lives in this one allocation
     d.xyzw = nullptr, d.idx = nullptr, d.triA = d.triB = d.triC = nullptr;
     d.morton = nullptr, d.order = d.child = d.parent = d.leaf_parent = nullptr, d.nodes = d.cut = d.cut_groups = nullptr;
+}
+
+void free_frame_scratch(FrameScratch& fs) {
+    for (auto& p : fs.stage) dfree(p);
+    fs.stage_elems = 0;
+    dfree(fs.ao_queue);
+    fs.ao_cap = 0;
 }
 
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).
@@ -164,6 +181,10 @@ int inv_ctx_create(int device, void* hip_stream, inv_ctx** out) {
 int inv_ctx_destroy(inv_ctx* ctx) {
     if (!ctx) return INV_OK;
     (void)hipSetDevice(ctx->device);
+    for (uint32_t i = 0; i < INV_MAX_FRAMES_IN_FLIGHT; i++) {
+        if (ctx->flight[i]) (void)hipStreamSynchronize(ctx->flight[i]), (void)hipStreamDestroy(ctx->flight[i]);
+        if (ctx->flight_done[i]) (void)hipEventDestroy(ctx->flight_done[i]);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return INV_OK;
@@ -392,10 +413,12 @@ int inv_scene_destroy(inv_scene* scene) {
     if (!scene) return INV_OK;
     (void)hipSetDevice(scene->ctx->device);
     (void)hipStreamSynchronize(scene->ctx->stream);
+    for (hipStream_t fs : scene->ctx->flight)
+        if (fs) (void)hipStreamSynchronize(fs); // draws in flight still read the scene
     free_device_scene(scene->d);
-    for (auto& p : scene->stage) dfree(p);
+    free_frame_scratch(scene->main);
+    for (auto& fsr : scene->flight) free_frame_scratch(fsr);
     dfree(scene->vs_stage);
-    dfree(scene->ao_queue);
     delete scene;
     return INV_OK;
 }
@@ -447,8 +470,12 @@ int inv_vertex_shader(inv_scene* scene, const inv_camera* cam, float* clip4, flo
 }
 
 // ---- the draw ----------------------------------------------------------------------------------------
-int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out) {
-    if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render: null argument");
+namespace {
+
+// One draw enqueued on `stream`, with `fs` as its staging and occlusion queue (nothing else may use `fs` on
+// another stream at the same time).
+int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_camera* cam, const inv_params* params,
+              const inv_outputs* out) {
     if (params->ao_rays != 0 && params->spp > 1)
         return fail(INV_ERR_UNSUPPORTED, "inv_render: ambient occlusion is defined for one sample per pixel");
     if (params->ao_rays > 4096) return fail(INV_ERR_ARG, "inv_render: at most 4096 ambient-occlusion rays per pixel");
@@ -476,43 +503,112 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
     if (out->on_device) {
         dev.color = (uint8_t*)out->color, dev.depth = (float*)out->depth, dev.primid = (uint32_t*)out->primid;
     } else {
-        if (f.npix > scene->stage_elems) {
-            for (auto& p : scene->stage) dfree(p);
-            scene->stage_elems = 0;
-            for (auto& p : scene->stage) HIP_TRY(hipMalloc(&p, f.npix * 4));
-            scene->stage_elems = f.npix;
+        if (f.npix > fs.stage_elems) {
+            HIP_TRY(hipStreamSynchronize(stream)); // an earlier draw may still write the old staging
+            for (auto& p : fs.stage) dfree(p);
+            fs.stage_elems = 0;
+            for (auto& p : fs.stage) HIP_TRY(hipMalloc(&p, f.npix * 4));
+            fs.stage_elems = f.npix;
         }
-        if (out->color) dev.color = (uint8_t*)scene->stage[0];
-        if (out->depth) dev.depth = (float*)scene->stage[1];
-        if (out->primid) dev.primid = (uint32_t*)scene->stage[2];
+        if (out->color) dev.color = (uint8_t*)fs.stage[0];
+        if (out->depth) dev.depth = (float*)fs.stage[1];
+        if (out->primid) dev.primid = (uint32_t*)fs.stage[2];
     }
     AoK ao = {0, 0.0f, nullptr, nullptr, nullptr};
     if (params->ao_rays) {
-        if (f.npix > scene->ao_cap) { // 256-byte header (counters), then at most one 48-byte record and one
-            dfree(scene->ao_queue);   // 4-byte accumulator per pixel
-            scene->ao_cap = 0;
-            HIP_TRY(hipMalloc((void**)&scene->ao_queue, f.npix * 52 + 256));
-            scene->ao_cap = f.npix;
+        if (f.npix > fs.ao_cap) { // 256-byte header (counters), then at most one 48-byte record and one
+            HIP_TRY(hipStreamSynchronize(stream)); // 4-byte accumulator per pixel; an earlier draw may still use the old queue
+            dfree(fs.ao_queue);
+            fs.ao_cap = 0;
+            HIP_TRY(hipMalloc((void**)&fs.ao_queue, f.npix * 52 + 256));
+            fs.ao_cap = f.npix;
         }
         ao.rays = params->ao_rays;
         ao.tmax = params->ao_tmax > 0.0f ? params->ao_tmax : scene->vertex_diag;
-        ao.count = (uint32_t*)scene->ao_queue;
-        ao.queue = scene->ao_queue + 64; // records start 256 bytes in
-        ao.acc = (uint32_t*)(ao.queue + (size_t)scene->ao_cap * 12);
-        HIP_TRY(hipMemsetAsync(ao.count, 0, 256, ctx->stream));
+        ao.count = (uint32_t*)fs.ao_queue;
+        ao.queue = fs.ao_queue + 64; // records start 256 bytes in
+        ao.acc = (uint32_t*)(ao.queue + (size_t)fs.ao_cap * 12);
+        HIP_TRY(hipMemsetAsync(ao.count, 0, 256, stream));
     }
     const bool brute = (params->flags & INV_BRUTE_FORCE) || !scene->d.has_bvh;
     if (brute)
-        HIP_TRY(launch_render_brute(ctx->stream, f, scene->d, ao, dev));
+        HIP_TRY(launch_render_brute(stream, f, scene->d, ao, dev));
     else
-        HIP_TRY(launch_render_bvh(ctx->stream, f, scene->d, ao, dev));
-    HIP_TRY(launch_ao(ctx->stream, f, scene->d, ao, dev));
+        HIP_TRY(launch_render_bvh(stream, f, scene->d, ao, dev));
+    HIP_TRY(launch_ao(stream, f, scene->d, ao, dev));
     if (!out->on_device) {
-        if (out->color) HIP_TRY(hipMemcpyAsync(out->color, dev.color, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->depth) HIP_TRY(hipMemcpyAsync(out->depth, dev.depth, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->primid) HIP_TRY(hipMemcpyAsync(out->primid, dev.primid, f.npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (out->color) HIP_TRY(hipMemcpyAsync(out->color, dev.color, f.npix * 4, hipMemcpyDeviceToHost, stream));
+        if (out->depth) HIP_TRY(hipMemcpyAsync(out->depth, dev.depth, f.npix * 4, hipMemcpyDeviceToHost, stream));
+        if (out->primid) HIP_TRY(hipMemcpyAsync(out->primid, dev.primid, f.npix * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
     }
+    return INV_OK;
+}
+
+// The slot's stream, created on first use (the context's device must be current).
+int flight_stream(inv_ctx* ctx, uint32_t slot, hipStream_t* s) {
+    if (slot >= INV_MAX_FRAMES_IN_FLIGHT) return fail(INV_ERR_ARG, "frame slot must be below INV_MAX_FRAMES_IN_FLIGHT");
+    if (!ctx->flight[slot]) {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(st);
+            return hip_fail(e, "hipEventCreateWithFlags");
+        }
+        ctx->flight[slot] = st, ctx->flight_done[slot] = ev;
+    }
+    *s = ctx->flight[slot];
+    return INV_OK;
+}
+
+} // namespace
+
+int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out) {
+    if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render: null argument");
+    return render_on(scene, scene->ctx->stream, scene->main, cam, params, out);
+}
+
+// ---- frames in flight ----------------------------------------------------------------------------------
+int inv_render_in_flight(inv_scene* scene, uint32_t slot, const inv_camera* cam, const inv_params* params,
+                         const inv_outputs* out) {
+    if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render_in_flight: null argument");
+    HIP_TRY(hipSetDevice(scene->ctx->device));
+    hipStream_t s = nullptr;
+    int rc = flight_stream(scene->ctx, slot, &s);
+    if (rc != INV_OK) return rc;
+    return render_on(scene, s, scene->flight[slot], cam, params, out);
+}
+
+int inv_frame_wait(inv_ctx* ctx, uint32_t slot) {
+    if (!ctx) return fail(INV_ERR_ARG, "inv_frame_wait: ctx is null");
+    if (slot >= INV_MAX_FRAMES_IN_FLIGHT) return fail(INV_ERR_ARG, "inv_frame_wait: frame slot must be below INV_MAX_FRAMES_IN_FLIGHT");
+    if (!ctx->flight[slot]) return INV_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->flight[slot]));
+    return INV_OK;
+}
+
+int inv_frames_join(inv_ctx* ctx) {
+    if (!ctx) return fail(INV_ERR_ARG, "inv_frames_join: ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < INV_MAX_FRAMES_IN_FLIGHT; i++) {
+        if (!ctx->flight[i]) continue;
+        HIP_TRY(hipEventRecord(ctx->flight_done[i], ctx->flight[i]));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->flight_done[i], 0));
+    }
+    return INV_OK;
+}
+
+int inv_frame_stream(inv_ctx* ctx, uint32_t slot, void** hip_stream) {
+    if (!ctx || !hip_stream) return fail(INV_ERR_ARG, "inv_frame_stream: null argument");
+    *hip_stream = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    int rc = flight_stream(ctx, slot, &s);
+    if (rc != INV_OK) return rc;
+    *hip_stream = (void*)s;
     return INV_OK;
 }
 

@@ -264,6 +264,85 @@ def test_device_outputs_on_torch_stream(bunny_scene, bunny_path):
     ctx.close()
 
 
+def test_frames_in_flight_match_the_oracle(oracle, bunny_path, bunny_mesh):
+    """Four different draws (turning model, different extents, jitter, occlusion rays) enqueued on the four frame
+    slots before anything is waited for, each into attachments of its own; then the same slots again with other
+    frames (a slot's second draw queues behind its first)."""
+    import torch
+    torch.cuda.set_device(0)
+    ctx = R.Context(0)
+    scene = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
+    jobs = [
+        (0.3, 1920, 1080, dict(flags=R.LAMBERT | R.INVERT)),
+        (1.0, 640, 360, dict(flags=R.LAMBERT, spp=4, seed=3)),
+        (2.5, 1280, 720, dict(flags=R.LAMBERT | R.INVERT, ao_rays=16)),
+        (3.75, 800, 600, dict(flags=R.LANE_TRAVERSAL)),
+        (4.1, 1024, 512, dict(flags=R.INVERT | R.RGBA)),
+        (0.0, 1920, 1080, dict(flags=0)),
+        (5.0, 320, 240, dict(flags=R.LAMBERT, ao_rays=5)),
+        (6.2, 512, 512, dict(flags=R.BRUTE_FORCE)),
+    ]
+    bufs = [torch.zeros(3, h * w, dtype=torch.int32, device="cuda") for (t, w, h, kw) in jobs]
+    torch.cuda.synchronize()  # the fills run on torch's stream, which the slots' streams do not wait for
+    for i, (t, w, h, kw) in enumerate(jobs):
+        planes = bufs[i]
+        scene.render_in_flight(i % R.api.MAX_FRAMES_IN_FLIGHT, R.camera_turntable(w, h, t), R.make_params(w, h, **kw),
+                               planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr())
+    for slot in range(R.api.MAX_FRAMES_IN_FLIGHT):
+        ctx.frame_wait(slot)  # only the slots' own streams are waited for
+    for planes, (t, w, h, kw) in zip(bufs, jobs):
+        host = planes.cpu().numpy()
+        got = (host[0].view(np.uint8).reshape(h, w, 4), host[1].view(np.float32).reshape(h, w),
+               host[2].view(np.uint32).reshape(h, w))
+        prm = R.make_params(w, h, **kw)
+        want = oracle.render_bvh(*bunny_mesh, oracle.camera_turntable(w, h, t), _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "in flight t=%.2f %dx%d" % (t, w, h))
+    # host-pointer outputs on a slot: the call itself waits for that slot
+    w, h = 333, 250
+    prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT)
+    got = scene.render_in_flight_host(2, R.camera_reference(w, h), prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "in flight, host outputs")
+    with pytest.raises(R.InvertError):
+        scene.render_in_flight(R.api.MAX_FRAMES_IN_FLIGHT, R.camera_reference(w, h), prm, bufs[0][0].data_ptr())
+    with pytest.raises(R.InvertError):
+        ctx.frame_wait(R.api.MAX_FRAMES_IN_FLIGHT)
+    scene.close()
+    ctx.close()
+
+
+def test_frames_join_orders_the_context_stream(bunny_path):
+    """inv_frames_join: a copy enqueued on the context's stream after the join sees the finished frames of every
+    slot, with no host wait in between."""
+    import torch
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream()
+    ctx = R.Context(0, stream=stream.cuda_stream)
+    scene = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
+    w, h = 1920, 1080
+    cam, prm = R.camera_reference(w, h), R.make_params(w, h)
+    assert ctx.frame_stream(0) != 0 and ctx.frame_stream(0) == ctx.frame_stream(0) != ctx.frame_stream(1)
+    frames = [torch.zeros(3, h * w, dtype=torch.int32, device="cuda") for _ in range(2)]
+    copies = [torch.zeros_like(f) for f in frames]
+    torch.cuda.synchronize()
+    for rep in range(8):  # the slots keep several draws queued
+        for slot, f in enumerate(frames):
+            scene.render_in_flight(slot, cam, prm, f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr())
+    ctx.frames_join()
+    with torch.cuda.stream(stream):
+        for c, f in zip(copies, frames):
+            c.copy_(f, non_blocking=True)
+    stream.synchronize()  # only the context's stream
+    want = common.golden_frame("bunny_1080_rect")
+    for c in copies:
+        host = c.cpu().numpy()
+        got = (host[0].view(np.uint8).reshape(h, w, 4), host[1].view(np.float32).reshape(h, w),
+               host[2].view(np.uint32).reshape(h, w))
+        common.assert_frames_equal(got, want, "after the join")
+    scene.close()
+    ctx.close()
+
+
 def test_errors(bunny_scene):
     cam = R.camera_reference(64, 64)
     with pytest.raises(R.InvertError):
