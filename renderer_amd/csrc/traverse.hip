@@ -47,6 +47,10 @@ constexpr int kRangeCap = 256;     // leaf ranges per tile
 // again and again, so it takes the larger one; the un-batched variant's smaller list leaves LDS for a fifth
 // workgroup per CU (tiles with more candidates than that fall back to the per-lane traversal).
 constexpr int kTileCapBatched = 256, kTileCapSparse = 128;
+#ifndef INV_FILL_RUN_CHUNKS
+#define INV_FILL_RUN_CHUNKS 128
+#endif
+constexpr uint32_t kFillRun = INV_FILL_RUN_CHUNKS; // 16-byte chunks a wave of the fill part stores per attachment and step
 
 struct BlockMap {
     uint32_t px, py;
@@ -662,7 +666,6 @@ __global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK
                                                          const float4* __restrict__ cut_groups, uint32_t ncut,
                                                          AoK ao, Outputs out) {
     __shared__ TileLds<NW, BATCHED ? kTileCapBatched : kTileCapSparse> S;
-    constexpr uint32_t NT = NW * 64;
     if (blockIdx.x < ntiles) {
         const uint32_t tx0 = (f.rx0 & ~7u) + (blockIdx.x % tiles_x) * 8u;
         const uint32_t ty0 = (f.ry0 & ~7u) + (blockIdx.x / tiles_x) * 8u;
@@ -678,41 +681,80 @@ __global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK
     const uint32_t hx1 = hx0 + tiles_x * 8u, hy1 = hy0 + (tiles_x ? ntiles / tiles_x : 0u) * 8u; // traced rectangle
     const uint32_t bg = background_pixel(f.flags);
     if (vec4) {
-        // 16 bytes (four pixels of a row) per lane and attachment, grid-stride: 1 KiB per wave-instruction
+        // 16 bytes (four pixels of a row) per lane, attachment and store: 1 KiB per wave-instruction.  A wave takes runs
+        // of kFillRun consecutive chunks; a run that lies in a row-major frame and touches no row of the traced
+        // rectangle (most do) is stored with one address per attachment and immediate offsets, without any per-lane
+        // pixel arithmetic.
+        // Write-through stores (sc1): the clear values leave the XCD's L2 as they are written instead of staying
+        // behind as dirty lines that push the scene out and are written back later (measured against plain and
+        // non-temporal stores: 12.8 -> 12.1 us per frame alone, 7.8 -> 6.8 us with two frames in flight).  The
+        // trailing s_nop keeps the next instruction off the data registers until the store has read them.
         const uint32_t row4 = (f.rowmajor ? f.w : f.tile) >> 2; // chunks per stored row
-        const uint32_t nchunks = (uint32_t)(f.npix >> 2);          // the host keeps npix near 2^31 at most, so c + stride cannot wrap
+        const uint32_t nchunks = (uint32_t)(f.npix >> 2);          // the host keeps npix near 2^31 at most, so c0 + stride cannot wrap
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const u32x4 c4 = {bg, bg, bg, bg}, p4 = {~0u, ~0u, ~0u, ~0u};
         const f32x4 d4 = {1.0f, 1.0f, 1.0f, 1.0f};
-        const uint32_t stride = fill_blocks * NT;
-        for (uint32_t c = (blockIdx.x - ntiles) * NT + threadIdx.x; c < nchunks; c += stride) {
-            uint32_t px, py;
-            if (f.rowmajor) {
-                // c / row4 without a division: row4_magic = floor(2^32 / row4) gives the quotient or one less
-                uint32_t q = __umulhi(c, row4_magic), r = c - q * row4;
-                if (r >= row4) q++, r -= row4;
-                px = r << 2, py = q;
-            } else {
-                const uint32_t per_tile = (f.tile * f.tile) >> 2;
-                const uint32_t slot = c / per_tile, rem = c % per_tile;
-                const uint32_t id = slot * f.nranks + f.rank;
-                if (id >= f.ntiles) continue;
-                px = (f.gx0 + id % f.tiles_x) * f.tile + ((rem % row4) << 2);
-                py = (f.gy0 + id / f.tiles_x) * f.tile + rem / row4;
-                if (px >= f.w || py >= f.h) continue;
-            }
-            if (px >= hx0 && px < hx1 && py >= hy0 && py < hy1) continue; // traced by the first part of the grid
-            // Write-through stores (sc1): the clear values leave the XCD's L2 as they are written instead of staying
-            // behind as dirty lines that push the scene out and are written back later (measured against plain and
-            // non-temporal stores: 12.8 -> 12.1 us per frame alone, 7.8 -> 6.8 us with two frames in flight).  The
-            // trailing s_nop keeps the next instruction off the data registers until the store has read them.
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x - ntiles) * NW + (threadIdx.x >> 6));
+        const uint32_t run_stride = fill_blocks * NW * kFillRun;
 #define INV_FILL_ST(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory")
-            if (out.depth) INV_FILL_ST(d4, (f32x4*)out.depth + c);
-            if (out.primid) INV_FILL_ST(p4, (u32x4*)out.primid + c);
-            if (out.color) INV_FILL_ST(c4, (u32x4*)out.color + c);
-#undef INV_FILL_ST
+#define INV_FILL_AT(v, p, off) \
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "n"(off) : "memory")
+#define INV_FILL_RUN(v, p)                                             \
+    do {                                                               \
+        INV_FILL_AT(v, p, 0);                                          \
+        if (kFillRun > 64u) INV_FILL_AT(v, p, 1024);                   \
+        if (kFillRun > 128u) {                                         \
+            INV_FILL_AT(v, p, 2048);                                   \
+            INV_FILL_AT(v, p, 3072);                                   \
+        }                                                              \
+    } while (0)
+        static_assert(kFillRun == 64 || kFillRun == 128 || kFillRun == 256, "immediate offsets reach 3 KiB");
+        for (uint32_t c0 = wave0 * kFillRun; c0 < nchunks; c0 += run_stride) { // wave-uniform
+            bool whole = f.rowmajor && c0 + kFillRun <= nchunks;
+            if (whole && hx1 > hx0 && hy1 > hy0) {
+                // first and last row of the run: c / row4 without a division (row4_magic = floor(2^32 / row4) gives
+                // the quotient or one less)
+                const uint32_t cl = c0 + kFillRun - 1u;
+                uint32_t q0 = __umulhi(c0, row4_magic), q1 = __umulhi(cl, row4_magic);
+                if (c0 - q0 * row4 >= row4) q0++;
+                if (cl - q1 * row4 >= row4) q1++;
+                whole = q1 < hy0 || q0 >= hy1;
+            }
+            if (whole) {
+                const uint32_t c = c0 + lane;
+                if (out.depth) INV_FILL_RUN(d4, (f32x4*)out.depth + c);
+                if (out.primid) INV_FILL_RUN(p4, (u32x4*)out.primid + c);
+                if (out.color) INV_FILL_RUN(c4, (u32x4*)out.color + c);
+                continue;
+            }
+            for (uint32_t j = 0; j < kFillRun; j += 64u) {
+                const uint32_t c = c0 + j + lane;
+                if (c >= nchunks) continue;
+                uint32_t px, py;
+                if (f.rowmajor) {
+                    uint32_t q = __umulhi(c, row4_magic), r = c - q * row4;
+                    if (r >= row4) q++, r -= row4;
+                    px = r << 2, py = q;
+                } else {
+                    const uint32_t per_tile = (f.tile * f.tile) >> 2;
+                    const uint32_t slot = c / per_tile, rem = c % per_tile;
+                    const uint32_t id = slot * f.nranks + f.rank;
+                    if (id >= f.ntiles) continue;
+                    px = (f.gx0 + id % f.tiles_x) * f.tile + ((rem % row4) << 2);
+                    py = (f.gy0 + id / f.tiles_x) * f.tile + rem / row4;
+                    if (px >= f.w || py >= f.h) continue;
+                }
+                if (px >= hx0 && px < hx1 && py >= hy0 && py < hy1) continue; // traced by the first part of the grid
+                if (out.depth) INV_FILL_ST(d4, (f32x4*)out.depth + c);
+                if (out.primid) INV_FILL_ST(p4, (u32x4*)out.primid + c);
+                if (out.color) INV_FILL_ST(c4, (u32x4*)out.color + c);
+            }
         }
+#undef INV_FILL_ST
+#undef INV_FILL_RUN
+#undef INV_FILL_AT
         return;
     }
     if (threadIdx.x >= 256) return; // the per-pixel path works in 32x8 pixel blocks of 256 lanes
@@ -928,7 +970,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     const bool dense = ntiles != 0 && (double)sc.ntri * 64.0 / rect_px > 48.0;
     const int nw = dense ? 4 : tile_waves();
     const uint32_t nt = (uint32_t)nw * 64u;
-    const uint64_t fill_work = vec4 ? ((f.npix >> 2) + nt - 1u) / nt : pixel_blocks;
+    const uint64_t fill_work = vec4 ? ((f.npix >> 2) + kFillRun * nw - 1u) / (kFillRun * nw) : pixel_blocks;
     const uint32_t fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
     const uint32_t row4 = std::max(1u, (f.rowmajor ? f.w : f.tile) >> 2);
     const uint32_t row4_magic = row4 == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / row4);

@@ -29,7 +29,7 @@ def main():
         cam = R.camera_reference(w, h)
         # PROBE_FLAGS: extra flag bits, e.g. 4194304 (with INV_TIMING_SWITCHES=1) skips the traced tiles: clear only
         prm = R.make_params(w, h, spp=spp, ao_rays=ao, flags=R.LAMBERT | R.INVERT | int(os.environ.get("PROBE_FLAGS", "0")))
-        for S in (1, 2, 3):
+        for S in (1, 2, 3, 4):
             planes = [torch.empty(3, w * h, dtype=torch.int32, device="cuda") for _ in range(S)]
             ptrs = [[p[i].data_ptr() for i in range(3)] for p in planes]
             best = 1e9
