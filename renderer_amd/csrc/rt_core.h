@@ -331,6 +331,19 @@ __device__ __forceinline__ uint32_t background_pixel(uint32_t flags) {
     return (flags & INV_INVERT) ? 0xFFFFFFFFu : 0xFF000000u;
 }
 
+// A pixel's attachment values are stored write-through (sc1), like the clear values: they leave the XCD's L2 as
+// they are written, so the end of the kernel has no dirty lines to write back.
+#ifndef INV_PIXEL_WT
+#define INV_PIXEL_WT 1
+#endif
+__device__ __forceinline__ void store_pixel(uint32_t* p, uint32_t v) {
+#if INV_PIXEL_WT
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 // Resolve and store one pixel whose samples were traced by this lane.  sr/sg/sb are the summed linear
 // colours.  With ambient occlusion on (one sample per pixel) a hit pixel is queued for the occlusion pass,
 // which writes its colour, instead.  Every active lane of the wave must call this together.
@@ -338,8 +351,8 @@ __device__ __forceinline__ void finish_pixel(const FrameK& f, const AoK& ao, con
                                              uint32_t pix, const Ray& ray0, const Hit& first, const float4& Bw,
                                              const float4& Cw /* records B, C of the winner; unused for a miss */,
                                              float sr, float sg, float sb, const float* T = kSrgbT) {
-    if (out.depth) out.depth[oi] = __uint_as_float((uint32_t)(first.key >> 32));
-    if (out.primid) out.primid[oi] = (uint32_t)first.key;
+    if (out.depth) store_pixel((uint32_t*)out.depth + oi, (uint32_t)(first.key >> 32));
+    if (out.primid) store_pixel(out.primid + oi, (uint32_t)first.key);
     if (ao.rays) {
         float o[3] = {0.0f, 0.0f, 0.0f}, n[3] = {0.0f, 0.0f, 0.0f};
         bool push = false;
@@ -352,7 +365,7 @@ __device__ __forceinline__ void finish_pixel(const FrameK& f, const AoK& ao, con
             const float n = (float)f.spp;
             sr = sr / n, sg = sg / n, sb = sb / n;
         }
-        ((uint32_t*)out.color)[oi] = pack_pixel(f.flags, sr, sg, sb, T);
+        store_pixel((uint32_t*)out.color + oi, pack_pixel(f.flags, sr, sg, sb, T));
     }
 }
 

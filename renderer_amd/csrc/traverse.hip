@@ -220,45 +220,71 @@ __global__ __launch_bounds__(256) void k_render_bvh(FrameK f, const float4* __re
 // ------------------------------------------------------------------------------------------------
 // tile kernel
 // ------------------------------------------------------------------------------------------------
-struct Plane {
-    float a, b, c, d; // a*x + b*y + c*z + d >= 0 inside
-};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ f32x2 both(float x) {
+    const f32x2 r = {x, x};
+    return r;
+}
+
+// Four side planes a*x + b*y + c*z + d >= 0 (inside), prepared for boxes given as sum and difference of their
+// corners: coefficients halved, their absolute values, and the offset raised by what growing the box adds.
+// Planes 0 and 1 sit in the two halves of the *01 members, planes 2 and 3 in *23 (packed fp32 arithmetic).
 struct Frustum {
-    Plane p[4];
+    f32x2 a01, b01, c01, aa01, ab01, ac01, d01;
+    f32x2 a23, b23, c23, aa23, ab23, ac23, d23;
 };
 
 // Side planes, in object space, of the pyramid of rays through framebuffer rectangle
-// [x0 - m, x1 + m] x [y0 - m, y1 + m] (pixels).  With clip = P * (V*M) * p and w_clip = -z_view:
-//   x_ndc >= xl  <=>  P00 * x_view + xl * z_view >= 0, and so on for the other three sides.
-__device__ __forceinline__ Frustum make_frustum(const FrameK& f, float x0, float y0, float x1, float y1) {
+// [x0 - m, x1 + m] x [y0 - m, y1 + m] (pixels), for boxes grown by `grow`.  With clip = P * (V*M) * p and
+// w_clip = -z_view:   x_ndc >= xl  <=>  P00 * x_view + xl * z_view >= 0, and so on for the other three sides.
+__device__ __forceinline__ Frustum make_frustum(const FrameK& f, float x0, float y0, float x1, float y1, float grow) {
     const float m = 0.0625f; // the 1/16 pixel of slack dwarfs the rounding of these reciprocal multiplies
     const float xl = (x0 - m) * f.inv_w2 - 1.0f, xr = (x1 + m) * f.inv_w2 - 1.0f;
     const float yl = (y0 - m) * f.inv_h2 - 1.0f, yr = (y1 + m) * f.inv_h2 - 1.0f;
     const float* r0 = f.mv;
     const float* r1 = f.mv + 4;
     const float* r2 = f.mv + 8;
+    float p[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        p[0][k] = f.p00 * r0[k] + xl * r2[k];
+        p[1][k] = -(f.p00 * r0[k] + xr * r2[k]);
+        p[2][k] = f.p11 * r1[k] + yl * r2[k];
+        p[3][k] = -(f.p11 * r1[k] + yr * r2[k]);
+    }
+    float ha[4], hb[4], hc[4], d[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ha[i] = 0.5f * p[i][0], hb[i] = 0.5f * p[i][1], hc[i] = 0.5f * p[i][2]; // exact
+        d[i] = p[i][3] + grow * ((fabsf(p[i][0]) + fabsf(p[i][1])) + fabsf(p[i][2]));
+    }
     Frustum fr;
-    fr.p[0] = {f.p00 * r0[0] + xl * r2[0], f.p00 * r0[1] + xl * r2[1], f.p00 * r0[2] + xl * r2[2], f.p00 * r0[3] + xl * r2[3]};
-    fr.p[1] = {-(f.p00 * r0[0] + xr * r2[0]), -(f.p00 * r0[1] + xr * r2[1]), -(f.p00 * r0[2] + xr * r2[2]), -(f.p00 * r0[3] + xr * r2[3])};
-    fr.p[2] = {f.p11 * r1[0] + yl * r2[0], f.p11 * r1[1] + yl * r2[1], f.p11 * r1[2] + yl * r2[2], f.p11 * r1[3] + yl * r2[3]};
-    fr.p[3] = {-(f.p11 * r1[0] + yr * r2[0]), -(f.p11 * r1[1] + yr * r2[1]), -(f.p11 * r1[2] + yr * r2[2]), -(f.p11 * r1[3] + yr * r2[3])};
+    fr.a01 = f32x2{ha[0], ha[1]}, fr.b01 = f32x2{hb[0], hb[1]}, fr.c01 = f32x2{hc[0], hc[1]};
+    fr.aa01 = f32x2{fabsf(ha[0]), fabsf(ha[1])}, fr.ab01 = f32x2{fabsf(hb[0]), fabsf(hb[1])};
+    fr.ac01 = f32x2{fabsf(hc[0]), fabsf(hc[1])}, fr.d01 = f32x2{d[0], d[1]};
+    fr.a23 = f32x2{ha[2], ha[3]}, fr.b23 = f32x2{hb[2], hb[3]}, fr.c23 = f32x2{hc[2], hc[3]};
+    fr.aa23 = f32x2{fabsf(ha[2]), fabsf(ha[3])}, fr.ab23 = f32x2{fabsf(hb[2]), fabsf(hb[3])};
+    fr.ac23 = f32x2{fabsf(hc[2]), fabsf(hc[3])}, fr.d23 = f32x2{d[2], d[3]};
     return fr;
 }
 
-// false only if the box, grown by `grow`, lies wholly outside one side plane
+// false only if the box, grown by the frustum's `grow`, lies wholly outside one side plane.  The largest value of a
+// plane function over the box is  a*(lo+hi)/2 + |a|*(hi-lo)/2 + ... + d: twelve packed fused multiply-adds for the
+// four planes.  The test only has to be conservative: its roundings (about 2^-23 of |a| * |coordinate| per term)
+// are thousands of times smaller than the 1/16 pixel the planes were moved outwards by, and a NaN (boxes with
+// infinite corners) counts as inside.
 __device__ __forceinline__ bool box_in_frustum(const Frustum& fr, float lx, float ly, float lz, float hx, float hy,
-                                               float hz, float grow) {
-    lx -= grow, ly -= grow, lz -= grow, hx += grow, hy += grow, hz += grow;
-    bool in = true;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const Plane& p = fr.p[i];
-        // largest value of the plane function over the box
-        const float v = (p.a * (p.a >= 0.0f ? hx : lx) + p.b * (p.b >= 0.0f ? hy : ly)) + (p.c * (p.c >= 0.0f ? hz : lz) + p.d);
-        in = in && !(v < 0.0f);
-    }
-    return in;
+                                               float hz) {
+    const f32x2 sx = both(lx + hx), sy = both(ly + hy), sz = both(lz + hz);
+    const f32x2 ex = both(hx - lx), ey = both(hy - ly), ez = both(hz - lz);
+#define INV_FMA2 __builtin_elementwise_fma
+    const f32x2 v01 = INV_FMA2(fr.a01, sx, INV_FMA2(fr.b01, sy, INV_FMA2(fr.c01, sz,
+                      INV_FMA2(fr.aa01, ex, INV_FMA2(fr.ab01, ey, INV_FMA2(fr.ac01, ez, fr.d01))))));
+    const f32x2 v23 = INV_FMA2(fr.a23, sx, INV_FMA2(fr.b23, sy, INV_FMA2(fr.c23, sz,
+                      INV_FMA2(fr.aa23, ex, INV_FMA2(fr.ab23, ey, INV_FMA2(fr.ac23, ez, fr.d23))))));
+#undef INV_FMA2
+    return !(v01.x < 0.0f) && !(v01.y < 0.0f) && !(v23.x < 0.0f) && !(v23.y < 0.0f);
 }
 
 // direction through framebuffer position (x, y) for culling: make_ray's formula with reciprocal multiplies
@@ -331,7 +357,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const float grow = 2.0f * f.pad;
     if (f.flags & kDebugSkipAll) return;
-    const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u));
+    const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u), grow);
     const bool stamps = (f.flags & kDebugCounts) && !(f.flags & kDebugSkipAfter2); // diagnostic build of the image
     unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
     if (stamps) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -348,7 +374,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
         bool in = false;
         if (g < ngroups) {
             const float4 lo = cut_groups[2 * (size_t)g], hi = cut_groups[2 * (size_t)g + 1];
-            in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, grow);
+            in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
         }
         const uint32_t at = wave_append(&S.n_groups, in, lane);
         if (in) S.groups[at] = g;
@@ -364,7 +390,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
             if (i < ncut) {
                 const float4 lo = cut[2 * (size_t)i], hi = cut[2 * (size_t)i + 1];
                 ref = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
-                const bool in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, grow);
+                const bool in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
                 to_range = in && count <= kRangeMax;
                 to_front = in && count > kRangeMax;
             }
@@ -399,8 +425,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                 const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
                 c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
                 lo = __float_as_uint(q3.z), hi = __float_as_uint(q3.w);
-                in0 = box_in_frustum(fr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, grow);
-                in1 = box_in_frustum(fr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, grow);
+                in0 = box_in_frustum(fr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                in1 = box_in_frustum(fr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
             }
             const uint32_t gamma = c0 & 0x7FFFFFFFu;
 #pragma unroll
@@ -438,9 +464,9 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     if (f.flags & kDebugSkipAfter1) return;
     if (S.n_ranges == 0 && !S.overflow && !(f.flags & kDebugCounts)) { // nothing in this tile: clear values
         if (wave == 0 && valid) {
-            if (out.depth) out.depth[oi] = 1.0f;
-            if (out.primid) out.primid[oi] = 0xFFFFFFFFu;
-            if (out.color) ((uint32_t*)out.color)[oi] = background_pixel(f.flags);
+            if (out.depth) store_pixel((uint32_t*)out.depth + oi, 0x3F800000u); // 1.0f
+            if (out.primid) store_pixel(out.primid + oi, 0xFFFFFFFFu);
+            if (out.color) store_pixel((uint32_t*)out.color + oi, background_pixel(f.flags));
         }
         return;
     }
@@ -479,7 +505,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                     const float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
                     keep = box_in_frustum(fr, fminf(A.x, fminf(bx, cx)), fminf(A.y, fminf(by, cy)),
                                           fminf(A.z, fminf(bz, cz)), fmaxf(A.x, fmaxf(bx, cx)), fmaxf(A.y, fmaxf(by, cy)),
-                                          fmaxf(A.z, fmaxf(bz, cz)), grow);
+                                          fmaxf(A.z, fmaxf(bz, cz)));
                     // det = e1 . (d x e2) is linear in d and every sample direction of the tile is a convex
                     // combination of the corner directions: if det is clearly negative at all four corners the
                     // triangle faces away from every ray of the tile (cull BACK, src/invert.cpp:1334).
