@@ -5,8 +5,9 @@
 
 One step = one frame of the workload rendered through the C ABI (include/invert.h) with every input
 (triangles, LBVH) and output buffer resident in HBM.  On one GPU the frames go round-robin to --frames-in-flight
-frame slots (default 2, the reference's MAX_FRAMES_IN_FLIGHT, src/invert.cpp:241): every frame is a whole draw into
-its slot's own attachments, and draws on different slots overlap on the GPU.  With N > 1 (launched by torch.distributed.run, one
+frame slots (default 3; the reference keeps MAX_FRAMES_IN_FLIGHT = 2, src/invert.cpp:241): every frame is a whole draw
+into its slot's own attachments, and draws on different slots overlap on the GPU (a fourth slot is slower again: the
+process has four hardware queues).  With N > 1 (launched by torch.distributed.run, one
 process per GPU) 32x32 screen tiles are dealt round-robin to the ranks, every rank renders its tiles, and the
 three attachments are gathered to rank 0 over RCCL and put together there; the same frame is rendered whatever N
 is, so scaling is "strong".  --composite sparse (default) deals out only the tiles under the scene's projected
@@ -114,7 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
                     help="one GPU: frame slots the frames are dealt to (1 = every draw on the context's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")

@@ -164,6 +164,19 @@ int inv_frames_join(inv_ctx* ctx);
 /* The slot's hipStream_t, for callers that record their own events on it or order their own streams after it. */
 int inv_frame_stream(inv_ctx* ctx, uint32_t slot, void** hip_stream);
 
+/* ---- several draws in one submission --------------------------------------------------------------------------- */
+/* vkQueueSubmit takes commandBufferCount command buffers (src/invert.cpp:661-672); the reference always hands it one.
+ * inv_render_batch enqueues `nframes` draws of one scene at once: frame i is drawn with cams[i] and params[i] into
+ * outs[i], exactly as inv_render would draw it (extents, flags and attachments may differ from frame to frame; the
+ * attachments of different frames must not overlap).  Frames the tile kernel can draw directly into device
+ * attachments (LBVH traversal, no occlusion rays, one rank) share launches, up to eight frames each, so that the
+ * dispatch gap and the wait for a frame's slowest tiles are paid once per launch instead of once per frame;
+ * anything else is drawn frame after frame.  `slot` is a frame slot (see inv_render_in_flight) or INV_CONTEXT_STREAM
+ * for the context's own stream. */
+#define INV_CONTEXT_STREAM 0xFFFFFFFFu
+int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const inv_camera* cams, const inv_params* params,
+                     const inv_outputs* outs);
+
 /* Number of pixels rank `rank` owns and, optionally, the tile ids in the order they are stored. */
 int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_ids, uint32_t tile_ids_cap,
                     uint32_t* ntiles);

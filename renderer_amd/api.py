@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("INVERT_HIP_LIB") or os.path.join(_HERE, "libinvert_hi
 
 LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL, SPARSE = 1, 2, 4, 8, 16, 32
 MAX_FRAMES_IN_FLIGHT = 4  # INV_MAX_FRAMES_IN_FLIGHT
+CONTEXT_STREAM = 0xFFFFFFFF  # INV_CONTEXT_STREAM
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(8)
 
 # every symbol include/invert.h declares
@@ -27,7 +28,7 @@ SYMBOLS = (
     "inv_camera_reference", "inv_camera_turntable",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
     "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
-    "inv_render_in_flight", "inv_frame_wait", "inv_frames_join", "inv_frame_stream",
+    "inv_render_batch", "inv_render_in_flight", "inv_frame_wait", "inv_frames_join", "inv_frame_stream",
     "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
     "inv_write_ppm", "inv_write_pfm", "inv_write_primid",
     "inv_last_error", "inv_version",
@@ -100,6 +101,7 @@ def lib():
     L.inv_vertex_shader.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int]
     L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_render_in_flight.argtypes = [vp, C.c_uint32, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
+    L.inv_render_batch.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.inv_frame_wait.argtypes = [vp, C.c_uint32]
     L.inv_frames_join.argtypes = [vp]
     L.inv_frame_stream.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
@@ -371,6 +373,20 @@ class Scene:
         if out is None:
             out = cache[key] = Outputs(color_ptr or None, depth_ptr or None, primid_ptr or None, 1)
         rc = lib().inv_render_in_flight(self._h, slot, C.byref(cam), C.byref(prm), C.byref(out))
+        if rc:
+            _chk(rc)
+
+    def make_batch(self, cams, prms, ptrs):
+        """Argument arrays for render_batch, built once and reused: cams and prms are sequences of Camera / Params,
+        ptrs a sequence of (colour, depth, primid) device pointers."""
+        n = len(cams)
+        return (n, (Camera * n)(*cams), (Params * n)(*prms),
+                (Outputs * n)(*[Outputs(c or None, d or None, p or None, 1) for c, d, p in ptrs]))
+
+    def render_batch(self, batch, slot: int = CONTEXT_STREAM):
+        """inv_render_batch: enqueue the draws of `batch` (from make_batch) on frame slot `slot` or the context's stream."""
+        n, cams, prms, outs = batch
+        rc = lib().inv_render_batch(self._h, slot, n, cams, prms, outs)
         if rc:
             _chk(rc)
 

@@ -474,8 +474,8 @@ namespace {
 
 // One draw enqueued on `stream`, with `fs` as its staging and occlusion queue (nothing else may use `fs` on
 // another stream at the same time).
-int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_camera* cam, const inv_params* params,
-              const inv_outputs* out) {
+// Argument checks of a draw and the per-frame constants the kernels take.
+int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_params* params, FrameK* fk) {
     if (params->ao_rays != 0 && params->spp > 1)
         return fail(INV_ERR_UNSUPPORTED, "inv_render: ambient occlusion is defined for one sample per pixel");
     if (params->ao_rays > 4096) return fail(INV_ERR_ARG, "inv_render: at most 4096 ambient-occlusion rays per pixel");
@@ -486,18 +486,24 @@ int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_
         static const bool allow = std::getenv("INV_TIMING_SWITCHES") != nullptr;
         if ((params->flags & ~known) && !allow) return fail(INV_ERR_ARG, "inv_render: unknown bits in params.flags");
     }
-    inv_ctx* ctx = scene->ctx;
-    FrameK f;
+    FrameK& f = *fk;
     std::memset(&f, 0, sizeof f);
     int rc = fill_layout(*params, &f);
     if (rc != INV_OK) return rc;
     if ((rc = frame_from_camera(*cam, scene->max_abs, &f)) != INV_OK) return rc;
-    {
-        uint32_t rect[4] = {0, 0, f.w, f.h};
-        if (scene->d.has_bvh) hit_rect(f, scene->d.bbox, rect);
-        f.rx0 = rect[0], f.ry0 = rect[1], f.rx1 = rect[2], f.ry1 = rect[3];
-        if (f.flags & INV_SPARSE) apply_sparse_grid(rect, &f);
-    }
+    uint32_t rect[4] = {0, 0, f.w, f.h};
+    if (scene->d.has_bvh) hit_rect(f, scene->d.bbox, rect);
+    f.rx0 = rect[0], f.ry0 = rect[1], f.rx1 = rect[2], f.ry1 = rect[3];
+    if (f.flags & INV_SPARSE) apply_sparse_grid(rect, &f);
+    return INV_OK;
+}
+
+int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_camera* cam, const inv_params* params,
+              const inv_outputs* out) {
+    inv_ctx* ctx = scene->ctx;
+    FrameK f;
+    int rc = prepare_frame(scene, cam, params, &f);
+    if (rc != INV_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     Outputs dev = {nullptr, nullptr, nullptr};
     if (out->on_device) {
@@ -579,6 +585,53 @@ int inv_render_in_flight(inv_scene* scene, uint32_t slot, const inv_camera* cam,
     int rc = flight_stream(scene->ctx, slot, &s);
     if (rc != INV_OK) return rc;
     return render_on(scene, s, scene->flight[slot], cam, params, out);
+}
+
+// ---- several draws in one submission ---------------------------------------------------------------------
+int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const inv_camera* cams, const inv_params* params,
+                     const inv_outputs* outs) {
+    if (!scene || (nframes && (!cams || !params || !outs))) return fail(INV_ERR_ARG, "inv_render_batch: null argument");
+    inv_ctx* ctx = scene->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = ctx->stream;
+    FrameScratch* fs = &scene->main;
+    if (slot != INV_CONTEXT_STREAM) {
+        int rc = flight_stream(ctx, slot, &stream);
+        if (rc != INV_OK) return rc;
+        fs = &scene->flight[slot];
+    }
+    // every frame is checked before anything is enqueued
+    FrameK fk[INV_BATCH_MAX];
+    Outputs dev[INV_BATCH_MAX];
+    bool one_launch = true;
+    const bool kept = nframes <= INV_BATCH_MAX; // the first pass's constants serve the launch
+    for (uint32_t i = 0; i < nframes; i++) {
+        FrameK& f = fk[i % INV_BATCH_MAX];
+        int rc = prepare_frame(scene, &cams[i], &params[i], &f);
+        if (rc != INV_OK) return rc;
+        const Outputs o = {(uint8_t*)outs[i].color, (float*)outs[i].depth, (uint32_t*)outs[i].primid};
+        one_launch = one_launch && outs[i].on_device && params[i].ao_rays == 0 && f.nranks == 1 &&
+                     tile_batchable(f, scene->d, o);
+    }
+    if (!one_launch) { // the same draws one after the other (occlusion rays, host attachments, other traversals ...)
+        for (uint32_t i = 0; i < nframes; i++) {
+            int rc = render_on(scene, stream, *fs, &cams[i], &params[i], &outs[i]);
+            if (rc != INV_OK) return rc;
+        }
+        return INV_OK;
+    }
+    for (uint32_t i0 = 0; i0 < nframes; i0 += INV_BATCH_MAX) {
+        const uint32_t n = std::min<uint32_t>(INV_BATCH_MAX, nframes - i0);
+        for (uint32_t i = 0; i < n; i++) {
+            if (!kept) {
+                int rc = prepare_frame(scene, &cams[i0 + i], &params[i0 + i], &fk[i]);
+                if (rc != INV_OK) return rc;
+            }
+            dev[i] = {(uint8_t*)outs[i0 + i].color, (float*)outs[i0 + i].depth, (uint32_t*)outs[i0 + i].primid};
+        }
+        HIP_TRY(launch_render_batch(stream, fk, dev, n, scene->d));
+    }
+    return INV_OK;
 }
 
 int inv_frame_wait(inv_ctx* ctx, uint32_t slot) {

@@ -81,6 +81,12 @@ hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const 
                            const float* translations, uint32_t ninst, float* A, float* B, float* C);
 hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
+// Several frames of one scene in one launch of the tile kernel (at most INV_BATCH_MAX; every frame must be
+// tile_batchable: LBVH scene, default traversal, not the dense variant; no occlusion pass).
+#define INV_BATCH_MAX 8
+bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out);
+hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
+                               const DeviceScene& sc);
 // Occlusion pass over the records the primary kernel queued (ao.rays > 0).
 hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 hipError_t launch_deinterleave_sparse(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,

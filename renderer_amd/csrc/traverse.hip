@@ -24,6 +24,7 @@
 // must lie in the triangle's padded box, reaches that test.  The winner is the minimum
 // (depth, primitive) key, so neither the visiting order nor the superset of candidates changes a pixel.
 #include <cstdlib>
+#include <cstring>
 
 #include "internal.h"
 #include "rt_core.h"
@@ -50,7 +51,8 @@ constexpr int kTileCapBatched = 256, kTileCapSparse = 128;
 #ifndef INV_FILL_RUN_CHUNKS
 #define INV_FILL_RUN_CHUNKS 128
 #endif
-constexpr uint32_t kFillRun = INV_FILL_RUN_CHUNKS; // 16-byte chunks a wave of the fill part stores per attachment and step
+constexpr uint32_t kFillRun = INV_FILL_RUN_CHUNKS;
+constexpr uint32_t kBatchMax = INV_BATCH_MAX; // frames per launch of the batch kernel // 16-byte chunks a wave of the fill part stores per attachment and step
 
 struct BlockMap {
     uint32_t px, py;
@@ -679,29 +681,40 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
         finish_pixel(f, ao, out, oi, pix, ray0, first, S.u.t.rec[ws][1], S.u.t.rec[ws][2], sr, sg, sb, S.srgb);
 }
 
-// Grid = [8x8 tiles of the hit rectangle] ++ [fill blocks].  The fill blocks store the clear values of every pixel
-// whose 8x8 tile is not in the first part, grid-stride: 16 bytes per lane when the row length and the buffer
-// addresses allow it (vec4), else one pixel per lane in 32x8 pixel blocks (two 128-byte lines per wave-instruction).
+// What the launcher works out for one frame of the tile kernel (host arithmetic, see plan_tile_frame).
+struct TilePlan {
+    uint32_t tiles_x, ntiles;   // 8x8 tiles of the traced rectangle
+    uint32_t fill_blocks;       // workgroups of the fill part
+    uint32_t pixel_blocks;      // 32x8 pixel blocks of the frame (fill part without 16-byte stores)
+    int vec4;                   // rows and addresses allow 16-byte stores
+    uint32_t row4_magic;        // floor(2^32 / chunks per row)
+};
+
+// One tile workgroup: block `tb` of the trace part of a frame's grid.
 template <int NW, bool BATCHED>
-__global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK f, uint32_t tiles_x, uint32_t ntiles,
-                                                         uint32_t fill_blocks, uint32_t pixel_blocks, int vec4,
-                                                         uint32_t row4_magic,
-                                                         const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                         const float4* __restrict__ TC, const float4* __restrict__ nodes,
-                                                         const float4* __restrict__ cut,
-                                                         const float4* __restrict__ cut_groups, uint32_t ncut,
-                                                         AoK ao, Outputs out) {
-    __shared__ TileLds<NW, BATCHED ? kTileCapBatched : kTileCapSparse> S;
-    if (blockIdx.x < ntiles) {
-        const uint32_t tx0 = (f.rx0 & ~7u) + (blockIdx.x % tiles_x) * 8u;
-        const uint32_t ty0 = (f.ry0 & ~7u) + (blockIdx.x / tiles_x) * 8u;
-        if (f.nranks > 1) { // block-uniform: a tile belongs to one rank
-            uint64_t dummy;
-            if (!out_index(f, tx0, ty0, dummy)) return;
-        }
-        trace_tile<NW, BATCHED>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
-        return;
+__device__ __forceinline__ void tile_block(const FrameK& f, const TilePlan& pl, uint32_t tb,
+                                           TileLds<NW, BATCHED ? kTileCapBatched : kTileCapSparse>& S,
+                                           const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                           const float4* __restrict__ TC, const float4* __restrict__ nodes,
+                                           const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
+                                           uint32_t ncut, const AoK& ao, const Outputs& out) {
+    const uint32_t tx0 = (f.rx0 & ~7u) + (tb % pl.tiles_x) * 8u;
+    const uint32_t ty0 = (f.ry0 & ~7u) + (tb / pl.tiles_x) * 8u;
+    if (f.nranks > 1) { // block-uniform: a tile belongs to one rank
+        uint64_t dummy;
+        if (!out_index(f, tx0, ty0, dummy)) return;
     }
+    trace_tile<NW, BATCHED>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+}
+
+// One workgroup of the fill part: block `fb` of pl.fill_blocks.  The fill blocks store the clear values of every
+// pixel whose 8x8 tile is not in the trace part, grid-stride: 16 bytes per lane when the row length and the buffer
+// addresses allow it (vec4), else one pixel per lane in 32x8 pixel blocks (two 128-byte lines per wave-instruction).
+template <int NW>
+__device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, uint32_t fb, const Outputs& out) {
+    const uint32_t tiles_x = pl.tiles_x, ntiles = pl.ntiles, fill_blocks = pl.fill_blocks;
+    const uint32_t pixel_blocks = pl.pixel_blocks, row4_magic = pl.row4_magic;
+    const int vec4 = pl.vec4;
     if (f.flags & kDebugSkipFill) return;
     const uint32_t hx0 = f.rx0 & ~7u, hy0 = f.ry0 & ~7u;
     const uint32_t hx1 = hx0 + tiles_x * 8u, hy1 = hy0 + (tiles_x ? ntiles / tiles_x : 0u) * 8u; // traced rectangle
@@ -722,7 +735,7 @@ __global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK
         const u32x4 c4 = {bg, bg, bg, bg}, p4 = {~0u, ~0u, ~0u, ~0u};
         const f32x4 d4 = {1.0f, 1.0f, 1.0f, 1.0f};
         const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t wave0 = __builtin_amdgcn_readfirstlane((blockIdx.x - ntiles) * NW + (threadIdx.x >> 6));
+        const uint32_t wave0 = __builtin_amdgcn_readfirstlane(fb * NW + (threadIdx.x >> 6));
         const uint32_t run_stride = fill_blocks * NW * kFillRun;
 #define INV_FILL_ST(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory")
 #define INV_FILL_AT(v, p, off) \
@@ -784,7 +797,7 @@ __global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK
         return;
     }
     if (threadIdx.x >= 256) return; // the per-pixel path works in 32x8 pixel blocks of 256 lanes
-    for (uint32_t b = blockIdx.x - ntiles; b < pixel_blocks; b += fill_blocks) {
+    for (uint32_t b = fb; b < pixel_blocks; b += fill_blocks) {
         const BlockOrigin o = block_origin(f, b);
         if (!o.live) continue;
         const uint32_t cx = o.x0 + (threadIdx.x & 31u), cy = o.y0 + (threadIdx.x >> 5);
@@ -795,6 +808,55 @@ __global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK
         if (out.primid) out.primid[i] = 0xFFFFFFFFu;
         if (out.color) ((uint32_t*)out.color)[i] = bg;
     }
+}
+
+// Grid = [8x8 tiles of the hit rectangle] ++ [fill blocks].
+template <int NW, bool BATCHED>
+__global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK f, TilePlan pl,
+                                                         const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                         const float4* __restrict__ TC, const float4* __restrict__ nodes,
+                                                         const float4* __restrict__ cut,
+                                                         const float4* __restrict__ cut_groups, uint32_t ncut,
+                                                         AoK ao, Outputs out) {
+    __shared__ TileLds<NW, BATCHED ? kTileCapBatched : kTileCapSparse> S;
+    if (blockIdx.x < pl.ntiles)
+        tile_block<NW, BATCHED>(f, pl, blockIdx.x, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+    else
+        fill_part<NW>(f, pl, blockIdx.x - pl.ntiles, out);
+}
+
+// Several frames in one launch (different cameras, extents and attachments, one scene).
+// Grid = [tiles of frame 0] ++ [fill blocks of frame 0] ++ [tiles of frame 1] ++ ... : workgroups start in grid
+// order, so the stores of one frame's fill part overlap the traced tiles of the next, and the dispatch gap and the
+// wait for the slowest tiles are paid once per launch.
+struct BatchFrame {
+    FrameK f;
+    TilePlan pl;
+    Outputs out;
+};
+struct Batch {
+    uint32_t nframes;
+    uint32_t block_end[kBatchMax]; // running sum of ntiles + fill_blocks
+    BatchFrame fr[kBatchMax];
+};
+static_assert(sizeof(Batch) <= 3072, "the batch travels in the kernel arguments");
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 5) void k_render_tile_batch(Batch b, const float4* __restrict__ TA,
+                                                                  const float4* __restrict__ TB,
+                                                                  const float4* __restrict__ TC,
+                                                                  const float4* __restrict__ nodes,
+                                                                  const float4* __restrict__ cut,
+                                                                  const float4* __restrict__ cut_groups, uint32_t ncut) {
+    __shared__ TileLds<NW, kTileCapSparse> S;
+    const AoK ao = {0, 0.0f, nullptr, nullptr, nullptr};
+    uint32_t i = 0, first = 0; // block-uniform: frame of this block and the first block of that frame
+    while (i + 1u < b.nframes && blockIdx.x >= b.block_end[i]) first = b.block_end[i], i++;
+    const uint32_t local = blockIdx.x - first;
+    if (local < b.fr[i].pl.ntiles)
+        tile_block<NW, false>(b.fr[i].f, b.fr[i].pl, local, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, b.fr[i].out);
+    else
+        fill_part<NW>(b.fr[i].f, b.fr[i].pl, local - b.fr[i].pl.ntiles, b.fr[i].out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -961,6 +1023,34 @@ static int tile_waves() {
     return nw;
 }
 
+// Grid terms of one frame of the tile kernel; `dense` says the frame needs the batched variant.
+static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Outputs& out, int nw, bool* dense) {
+    TilePlan pl;
+    if (f.rowmajor)
+        pl.pixel_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
+    else
+        pl.pixel_blocks = f.slots * (f.tile >> 5) * (f.tile >> 3);
+    const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+    pl.vec4 = (f.w % 4u == 0) && aligned16(out.color) && aligned16(out.depth) && aligned16(out.primid);
+    uint32_t tiles_x = 0, tiles_y = 0;
+    if (f.rx1 > f.rx0 && f.ry1 > f.ry0) {
+        tiles_x = ((f.rx1 + 7u) >> 3) - (f.rx0 >> 3);
+        tiles_y = ((f.ry1 + 7u) >> 3) - (f.ry0 >> 3);
+    }
+    pl.tiles_x = tiles_x, pl.ntiles = tiles_x * tiles_y;
+    // Where triangles are much smaller than a pixel an 8x8 tile has more candidates than the record list holds:
+    // such frames take the variant that works through them in batches.
+    const double rect_px = (double)(f.rx1 - f.rx0) * (double)(f.ry1 - f.ry0);
+    *dense = pl.ntiles != 0 && (double)sc.ntri * 64.0 / rect_px > 48.0;
+    if (*dense) nw = 4;
+    const uint32_t nt = (uint32_t)nw * 64u;
+    const uint64_t fill_work = pl.vec4 ? ((f.npix >> 2) + kFillRun * nw - 1u) / (kFillRun * nw) : pl.pixel_blocks;
+    pl.fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
+    const uint32_t row4 = std::max(1u, (f.rowmajor ? f.w : f.tile) >> 2);
+    pl.row4_magic = row4 == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / row4);
+    return pl;
+}
+
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao,
                              const Outputs& out) {
     if (f.npix == 0) return hipSuccess;
@@ -977,46 +1067,55 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
                            (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, ao, out);
         return hipGetLastError();
     }
-    uint32_t pixel_blocks;
-    if (f.rowmajor)
-        pixel_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
-    else
-        pixel_blocks = f.slots * (f.tile >> 5) * (f.tile >> 3);
-    const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
-    const int vec4 = (f.w % 4u == 0) && aligned16(out.color) && aligned16(out.depth) && aligned16(out.primid);
-    uint32_t tiles_x = 0, tiles_y = 0;
-    if (f.rx1 > f.rx0 && f.ry1 > f.ry0) {
-        tiles_x = ((f.rx1 + 7u) >> 3) - (f.rx0 >> 3);
-        tiles_y = ((f.ry1 + 7u) >> 3) - (f.ry0 >> 3);
-    }
-    const uint32_t ntiles = tiles_x * tiles_y;
-    // Where triangles are much smaller than a pixel an 8x8 tile has more candidates than the record list holds:
-    // such frames take the variant that works through them in batches.
-    const double rect_px = (double)(f.rx1 - f.rx0) * (double)(f.ry1 - f.ry0);
-    const bool dense = ntiles != 0 && (double)sc.ntri * 64.0 / rect_px > 48.0;
-    const int nw = dense ? 4 : tile_waves();
-    const uint32_t nt = (uint32_t)nw * 64u;
-    const uint64_t fill_work = vec4 ? ((f.npix >> 2) + kFillRun * nw - 1u) / (kFillRun * nw) : pixel_blocks;
-    const uint32_t fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
-    const uint32_t row4 = std::max(1u, (f.rowmajor ? f.w : f.tile) >> 2);
-    const uint32_t row4_magic = row4 == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / row4);
-#define INV_LAUNCH_TILE(NW)                                                                                          \
-    hipLaunchKernelGGL((k_render_tile<NW, false>), dim3(ntiles + fill_blocks), dim3(NW * 64), 0, s, f, tiles_x, ntiles, \
-                       fill_blocks, pixel_blocks, vec4, row4_magic, (const float4*)sc.triA, (const float4*)sc.triB, \
-                       (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,                        \
-                       (const float4*)sc.cut_groups, sc.ncut, ao, out)
+    bool dense = false;
+    const int nw = tile_waves();
+    const TilePlan pl = plan_tile_frame(f, sc, out, nw, &dense);
+#define INV_LAUNCH_TILE(NW, B)                                                                                          \
+    hipLaunchKernelGGL((k_render_tile<NW, B>), dim3(pl.ntiles + pl.fill_blocks), dim3(NW * 64), 0, s, f, pl,            \
+                       (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, \
+                       (const float4*)sc.cut, (const float4*)sc.cut_groups, sc.ncut, ao, out)
     if (dense)
-        hipLaunchKernelGGL((k_render_tile<4, true>), dim3(ntiles + fill_blocks), dim3(256), 0, s, f, tiles_x, ntiles,
-                           fill_blocks, pixel_blocks, vec4, row4_magic, (const float4*)sc.triA, (const float4*)sc.triB,
-                           (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,
-                           (const float4*)sc.cut_groups, sc.ncut, ao, out);
+        INV_LAUNCH_TILE(4, true);
     else if (nw == 8)
-        INV_LAUNCH_TILE(8);
+        INV_LAUNCH_TILE(8, false);
     else if (nw == 16)
-        INV_LAUNCH_TILE(16);
+        INV_LAUNCH_TILE(16, false);
     else
-        INV_LAUNCH_TILE(4);
+        INV_LAUNCH_TILE(4, false);
 #undef INV_LAUNCH_TILE
+    return hipGetLastError();
+}
+
+bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out) {
+    if (f.npix == 0 || !sc.has_bvh || sc.height > (uint32_t)kStack) return false;
+    if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE)) return false;
+    bool dense = false;
+    (void)plan_tile_frame(f, sc, out, 4, &dense);
+    return !dense;
+}
+
+hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
+                               const DeviceScene& sc) {
+    if (n == 0) return hipSuccess;
+    if (n > kBatchMax) return hipErrorInvalidValue;
+    Batch b;
+    std::memset(&b, 0, sizeof b);
+    b.nframes = n;
+    uint32_t blocks = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        bool dense = false;
+        b.fr[i].f = frames[i];
+        b.fr[i].out = outs[i];
+        b.fr[i].pl = plan_tile_frame(frames[i], sc, outs[i], 4, &dense);
+        if (dense) return hipErrorInvalidValue; // the caller asks tile_batchable first
+        blocks += b.fr[i].pl.ntiles + b.fr[i].pl.fill_blocks;
+        b.block_end[i] = blocks;
+    }
+    for (uint32_t i = n; i < kBatchMax; i++) b.block_end[i] = blocks;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_render_tile_batch<4>), dim3(blocks), dim3(256), 0, s, b, (const float4*)sc.triA,
+                       (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,
+                       (const float4*)sc.cut_groups, sc.ncut);
     return hipGetLastError();
 }
 

@@ -311,6 +311,55 @@ def test_frames_in_flight_match_the_oracle(oracle, bunny_path, bunny_mesh):
     ctx.close()
 
 
+def test_batched_draws_match_the_oracle(oracle, bunny_path, bunny_mesh):
+    """inv_render_batch: frames of different cameras, extents and flags in one submission.  The first batch shares
+    launches of the tile kernel (eleven frames: one launch of eight and one of three), the second contains frames that
+    cannot (occlusion rays, per-lane traversal) and is drawn frame after frame; both on a frame slot and on the
+    context's stream."""
+    import torch
+    torch.cuda.set_device(0)
+    ctx = R.Context(0)
+    scene = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
+    shared = [(0.1 * i, w, h, kw) for i, (w, h, kw) in enumerate([
+        (1920, 1080, dict(flags=R.LAMBERT | R.INVERT)), (640, 360, dict(flags=R.LAMBERT, spp=4, seed=3)),
+        (1280, 720, dict(flags=0)), (333, 250, dict(flags=R.INVERT | R.RGBA)), (64, 64, dict(flags=R.LAMBERT)),
+        (1920, 1080, dict(flags=0)), (800, 600, dict(flags=R.LAMBERT, spp=2, seed=9)), (1001, 3, dict(flags=0)),
+        (512, 512, dict(flags=R.INVERT)), (1024, 768, dict(flags=R.LAMBERT | R.INVERT, spp=5)), (7, 5, dict(flags=0)),
+    ])]
+    mixed = [(0.7, 640, 360, dict(flags=R.LAMBERT, ao_rays=8)), (1.9, 800, 600, dict(flags=R.LANE_TRAVERSAL)),
+             (2.2, 512, 512, dict(flags=R.LAMBERT | R.INVERT))]
+    for jobs, slot in ((shared, 1), (mixed, 2), (shared[:3], R.api.CONTEXT_STREAM)):
+        bufs = [torch.zeros(3, h * w, dtype=torch.int32, device="cuda") for (t, w, h, kw) in jobs]
+        torch.cuda.synchronize()
+        batch = scene.make_batch([R.camera_turntable(w, h, t) for (t, w, h, kw) in jobs],
+                                 [R.make_params(w, h, **kw) for (t, w, h, kw) in jobs],
+                                 [(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr()) for b in bufs])
+        scene.render_batch(batch, slot)
+        if slot == R.api.CONTEXT_STREAM:
+            ctx.synchronize()
+        else:
+            ctx.frame_wait(slot)
+        for planes, (t, w, h, kw) in zip(bufs, jobs):
+            host = planes.cpu().numpy()
+            got = (host[0].view(np.uint8).reshape(h, w, 4), host[1].view(np.float32).reshape(h, w),
+                   host[2].view(np.uint32).reshape(h, w))
+            prm = R.make_params(w, h, **kw)
+            want = oracle.render_bvh(*bunny_mesh, oracle.camera_turntable(w, h, t), _oracle_params(oracle, prm))
+            common.assert_frames_equal(got, want, "batch t=%.2f %dx%d" % (t, w, h))
+    # a bad frame anywhere in the batch refuses the whole batch before anything is drawn
+    bufs = [torch.zeros(3, 64 * 64, dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    bad = scene.make_batch([R.camera_reference(64, 64)] * 2, [R.make_params(64, 64), R.make_params(64, 64, tile=12)],
+                           [(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr()) for b in bufs])
+    with pytest.raises(R.InvertError):
+        scene.render_batch(bad)
+    ctx.synchronize()
+    assert int(bufs[0].abs().sum()) == 0
+    scene.render_batch(scene.make_batch([], [], []))  # an empty batch is nothing
+    scene.close()
+    ctx.close()
+
+
 def test_frames_join_orders_the_context_stream(bunny_path):
     """inv_frames_join: a copy enqueued on the context's stream after the join sees the finished frames of every
     slot, with no host wait in between."""

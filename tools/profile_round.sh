@@ -17,6 +17,8 @@ timeout -k 10 200 python3 bench.py --workload bunny_1080p_ao64 > "$O/bench_ao64.
 (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- $B > /dev/null 2>&1)
 (cd /tmp && timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_ao" -- $B --workload bunny_1080p_ao64 > /dev/null 2>&1)
 timeout -k 10 120 python3 tools/phase_timing.py > "$O/phase_timing.txt" 2>&1
+timeout -k 10 120 python3 tools/phase_timing.py --frames-in-flight 3 > "$O/phase_timing_3_in_flight.txt" 2>&1
+timeout -k 10 120 tools/micro/host_loop "$(python3 -c 'import sys; sys.path.insert(0, "tests"); import objfmt; print(objfmt.bunny_obj_path())')" > "$O/host_loop.txt" 2>&1
 timeout -k 10 120 python3 tools/tile_stats.py > "$O/tile_stats.txt" 2>&1
 bash tools/pmc_phases.sh > /dev/null 2>&1 && cp gpurun_out/pmc_phases.txt "$O/pmc_phases.txt"
 timeout -k 10 300 python3 tools/config4.py > "$O/config4.txt" 2>&1

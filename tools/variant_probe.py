@@ -43,6 +43,26 @@ def main():
             line.append("%s x%d %7.2f us" % (name, S, best))
         line.append(hashlib.sha1(planes[0].cpu().numpy().tobytes()).hexdigest()[:8])
     print("  ".join(line), flush=True)
+    # several frames per launch (inv_render_batch), each into attachments of its own
+    w, h = 1920, 1080
+    cam, prm = R.camera_reference(w, h), R.make_params(w, h, flags=R.LAMBERT | R.INVERT | int(os.environ.get("PROBE_FLAGS", "0")))
+    for F in (2, 4, 8):
+        line = ["  %d frames per launch:" % F]
+        for S in (1, 2, 3):
+            planes = [torch.empty(3, w * h, dtype=torch.int32, device="cuda") for _ in range(S * F)]
+            batches = [scene.make_batch([cam] * F, [prm] * F, [(p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr())
+                                                                 for p in planes[j * F:(j + 1) * F]]) for j in range(S)]
+            K, best = 2400 // F, 1e9
+            for rep in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(K):
+                    scene.render_batch(batches[i % S], i % S)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / (K * F) * 1e6)
+            line.append("x%d %6.2f us" % (S, best))
+        line.append(hashlib.sha1(planes[-1].cpu().numpy().tobytes()).hexdigest()[:8])
+        print("  ".join(line), flush=True)
     scene.close()
     ctx.close()
 
