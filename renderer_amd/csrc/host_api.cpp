@@ -482,7 +482,7 @@ int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_param
     {
         // Bits above the INV_* flags switch parts of the kernels off for timing experiments (tools/phase_timing.py,
         // tools/tile_stats.py) and make the images wrong: they are refused unless INV_TIMING_SWITCHES is set.
-        constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE;
+        constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE | INV_BLOCKS;
         static const bool allow = std::getenv("INV_TIMING_SWITCHES") != nullptr;
         if ((params->flags & ~known) && !allow) return fail(INV_ERR_ARG, "inv_render: unknown bits in params.flags");
     }

@@ -276,17 +276,34 @@ __device__ __forceinline__ Frustum make_frustum(const FrameK& f, float x0, float
 // four planes.  The test only has to be conservative: its roundings (about 2^-23 of |a| * |coordinate| per term)
 // are thousands of times smaller than the 1/16 pixel the planes were moved outwards by, and a NaN (boxes with
 // infinite corners) counts as inside.
-__device__ __forceinline__ bool box_in_frustum(const Frustum& fr, float lx, float ly, float lz, float hx, float hy,
-                                               float hz) {
+__device__ __forceinline__ void box_planes(const Frustum& fr, float lx, float ly, float lz, float hx, float hy, float hz,
+                                           f32x2& v01, f32x2& v23) {
     const f32x2 sx = both(lx + hx), sy = both(ly + hy), sz = both(lz + hz);
     const f32x2 ex = both(hx - lx), ey = both(hy - ly), ez = both(hz - lz);
 #define INV_FMA2 __builtin_elementwise_fma
-    const f32x2 v01 = INV_FMA2(fr.a01, sx, INV_FMA2(fr.b01, sy, INV_FMA2(fr.c01, sz,
-                      INV_FMA2(fr.aa01, ex, INV_FMA2(fr.ab01, ey, INV_FMA2(fr.ac01, ez, fr.d01))))));
-    const f32x2 v23 = INV_FMA2(fr.a23, sx, INV_FMA2(fr.b23, sy, INV_FMA2(fr.c23, sz,
-                      INV_FMA2(fr.aa23, ex, INV_FMA2(fr.ab23, ey, INV_FMA2(fr.ac23, ez, fr.d23))))));
+    v01 = INV_FMA2(fr.a01, sx, INV_FMA2(fr.b01, sy, INV_FMA2(fr.c01, sz,
+          INV_FMA2(fr.aa01, ex, INV_FMA2(fr.ab01, ey, INV_FMA2(fr.ac01, ez, fr.d01))))));
+    v23 = INV_FMA2(fr.a23, sx, INV_FMA2(fr.b23, sy, INV_FMA2(fr.c23, sz,
+          INV_FMA2(fr.aa23, ex, INV_FMA2(fr.ab23, ey, INV_FMA2(fr.ac23, ez, fr.d23))))));
 #undef INV_FMA2
+}
+
+__device__ __forceinline__ bool box_in_frustum(const Frustum& fr, float lx, float ly, float lz, float hx, float hy,
+                                               float hz) {
+    f32x2 v01, v23;
+    box_planes(fr, lx, ly, lz, hx, hy, hz, v01, v23);
     return !(v01.x < 0.0f) && !(v01.y < 0.0f) && !(v23.x < 0.0f) && !(v23.y < 0.0f);
+}
+
+// Which 8x8 quadrants of a 16x16 pixel block a box can touch, given the planes of make_frustum(xm, ym, xm, ym) for
+// the block's centre (xm, ym): plane 0 keeps x >= xm - slack (right half), 1 keeps x <= xm + slack (left), 2 keeps
+// y >= ym - slack (lower rows), 3 keeps y <= ym + slack (upper rows).  Bit q = quadrant (q & 1 = right, q >> 1 = lower).
+__device__ __forceinline__ uint32_t box_quadrants(const Frustum& mid, float lx, float ly, float lz, float hx, float hy,
+                                                  float hz) {
+    f32x2 v01, v23;
+    box_planes(mid, lx, ly, lz, hx, hy, hz, v01, v23);
+    const uint32_t right = !(v01.x < 0.0f), left = !(v01.y < 0.0f), lower = !(v23.x < 0.0f), upper = !(v23.y < 0.0f);
+    return (left & upper) | ((right & upper) << 1) | ((left & lower) << 2) | ((right & lower) << 3);
 }
 
 // direction through framebuffer position (x, y) for culling: make_ray's formula with reciprocal multiplies
@@ -681,43 +698,398 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
         finish_pixel(f, ao, out, oi, pix, ray0, first, S.u.t.rec[ws][1], S.u.t.rec[ws][2], sr, sg, sb, S.srgb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 16x16 pixel blocks: the un-batched path of the tile kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int kBlockCap = 256; // candidate triangle records per 16x16 block
+
+struct BlockLds {
+    union {
+        struct {
+            uint32_t frontier[2][kFrontierCap];
+            uint2 ranges[kRangeCap];      // (first sorted triangle, count <= kRangeMax)
+            float4 rec[kBlockCap][3];     // candidate records A, B, C that survived the per-triangle test
+            float4 pre[kBlockCap][3];     // their folded terms for the cheap inside test (fold_triangle)
+        } t;
+        uint32_t stack[kStack * 128]; // fallback: per-lane traversal, one column per lane, two waves at a time
+    } u;
+    float srgb[256];            // copy of the sRGB threshold table
+    uint32_t quad[kBlockCap];   // per record: the quadrants (bit = wave) its box can touch
+    uint32_t groups[kCutCap / kCutGroup]; // cut groups whose box meets the block's frustum
+    uint32_t n_groups;
+    uint32_t n_front[2];
+    uint32_t n_ranges;
+    uint32_t n_rec;
+    uint32_t overflow; // more subtrees, leaf ranges or records than the lists hold: per-lane traversal instead
+};
+
+// One workgroup of four waves per 16x16 pixel block of the rectangle that can contain hits.  Phases 1 and 2 find the
+// block's candidate triangles as a whole workgroup (cut groups -> cut records -> subtrees -> one triangle per lane
+// against the block's frustum and facing) and note for every record which 8x8 quadrants its box can touch.  In phase
+// 3 every wave owns one quadrant: it walks the records of that quadrant (wave-uniform loop, records read from LDS as
+// broadcasts), runs the cheap inside test for its 64 pixels, the full Moller-Trumbore test where that says yes, and
+// shades and stores its own pixels: no exchange between waves.
+__device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32_t tx0, uint32_t ty0,
+                                            const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                            const float4* __restrict__ TC, const float4* __restrict__ nodes,
+                                            const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
+                                            uint32_t ncut, const AoK& ao, const Outputs& out) {
+    constexpr uint32_t NT = 256;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const float grow = 2.0f * f.pad;
+    if (f.flags & kDebugSkipAll) return;
+    const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 16u), (float)(ty0 + 16u), grow);
+    const bool stamps = (f.flags & kDebugCounts) && !(f.flags & kDebugSkipAfter2); // diagnostic build of the image
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0, ta = 0, tb = 0, tc = 0;
+    if (stamps) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+
+    // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
+    //      is still a subtree after that is opened breadth-first ----
+    if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
+    const float srgb_entry = kSrgbT[tid]; // stored to LDS later: the load stays in flight behind the first steps
+    __syncthreads();
+    if (stamps) ta = __builtin_amdgcn_s_memtime();
+    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
+    for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
+        const uint32_t g = base + tid;
+        bool in = false;
+        if (g < ngroups) {
+            const float4 lo = cut_groups[2 * (size_t)g], hi = cut_groups[2 * (size_t)g + 1];
+            in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+        }
+        const uint32_t at = wave_append(&S.n_groups, in, lane);
+        if (in) S.groups[at] = g;
+    }
+    __syncthreads();
+    if (stamps) tb = __builtin_amdgcn_s_memtime();
+    const uint32_t nsel = S.n_groups * kCutGroup;
+    for (uint32_t base = 0; base < nsel; base += 2u * NT) { // block-uniform trip count; two records per lane and
+        float4 lo[2], hi[2];                                // trip, both loads in flight before the first test
+        bool have[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t q = base + (uint32_t)u * NT + tid;
+            have[u] = false;
+            if (q < nsel) {
+                const uint32_t i = S.groups[q / kCutGroup] * kCutGroup + q % kCutGroup;
+                if (i < ncut) have[u] = true, lo[u] = cut[2 * (size_t)i], hi[u] = cut[2 * (size_t)i + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (base + (uint32_t)u * NT >= nsel) break; // block-uniform
+            bool to_range = false, to_front = false;
+            uint32_t ref = 0, count = 0;
+            if (have[u]) {
+                ref = __float_as_uint(lo[u].w), count = __float_as_uint(hi[u].w);
+                const bool in = box_in_frustum(fr, lo[u].x, lo[u].y, lo[u].z, hi[u].x, hi[u].y, hi[u].z);
+                to_range = in && count <= kRangeMax;
+                to_front = in && count > kRangeMax;
+            }
+            const uint32_t ar = wave_append(&S.n_ranges, to_range, lane);
+            if (to_range) {
+                if (ar < (uint32_t)kRangeCap)
+                    S.u.t.ranges[ar] = make_uint2(ref, count);
+                else
+                    S.overflow = 1;
+            }
+            const uint32_t af = wave_append(&S.n_front[0], to_front, lane);
+            if (to_front) {
+                if (af < (uint32_t)kFrontierCap)
+                    S.u.t.frontier[0][af] = ref;
+                else
+                    S.overflow = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (stamps) tc = __builtin_amdgcn_s_memtime();
+    int cur = 0;
+    for (;;) { // only scenes whose cut is capped still have subtrees to open here
+        const uint32_t n = S.n_front[cur];
+        if (n == 0 || S.overflow) break;
+        for (uint32_t base = 0; base < n; base += NT) {
+            const uint32_t q = base + tid;
+            bool in0 = false, in1 = false;
+            uint32_t c0 = 0, c1 = 0, lo = 0, hi = 0;
+            if (q < n) {
+                const uint32_t node = S.u.t.frontier[cur][q];
+                const float4 q0 = nodes[4 * (size_t)node + 0], q1 = nodes[4 * (size_t)node + 1];
+                const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
+                c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                lo = __float_as_uint(q3.z), hi = __float_as_uint(q3.w);
+                in0 = box_in_frustum(fr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                in1 = box_in_frustum(fr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            }
+            const uint32_t gamma = c0 & 0x7FFFFFFFu;
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const bool in = side ? in1 : in0;
+                const uint32_t c = side ? c1 : c0;
+                const uint32_t first = side ? gamma + 1u : lo;
+                const uint32_t count = side ? hi - gamma : gamma - lo + 1u;
+                const bool small = (c & 0x80000000u) || count <= kRangeMax;
+                const uint32_t ar = wave_append(&S.n_ranges, in && small, lane);
+                if (in && small) {
+                    if (ar < (uint32_t)kRangeCap)
+                        S.u.t.ranges[ar] = make_uint2(first, count);
+                    else
+                        S.overflow = 1;
+                }
+                const uint32_t af = wave_append(&S.n_front[cur ^ 1], in && !small, lane);
+                if (in && !small) {
+                    if (af < (uint32_t)kFrontierCap)
+                        S.u.t.frontier[cur ^ 1][af] = c;
+                    else
+                        S.overflow = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) S.n_front[cur] = 0;
+        cur ^= 1;
+        __syncthreads();
+    }
+
+    // this lane's pixel: wave w owns quadrant (w & 1, w >> 1) of the block
+    const uint32_t px = tx0 + ((wave & 1u) << 3) + (lane & 7u), py = ty0 + ((wave >> 1) << 3) + (lane >> 3);
+    uint64_t oi = 0;
+    const bool valid = px < f.w && py < f.h && out_index(f, px, py, oi);
+    if (f.flags & kDebugSkipAfter1) return;
+    if (S.n_ranges == 0 && !S.overflow && !(f.flags & kDebugCounts)) { // nothing in this block: clear values
+        if (valid) {
+            if (out.depth) store_pixel((uint32_t*)out.depth + oi, 0x3F800000u); // 1.0f
+            if (out.primid) store_pixel(out.primid + oi, 0xFFFFFFFFu);
+            if (out.color) store_pixel((uint32_t*)out.color + oi, background_pixel(f.flags));
+        }
+        return;
+    }
+    if (stamps) t1 = __builtin_amdgcn_s_memtime();
+    S.srgb[tid] = srgb_entry;
+    // ---- phase 2: one candidate triangle per lane against the block's frustum and facing ----
+    const uint32_t nranges = S.n_ranges;
+    if (!S.overflow) {
+        const Frustum mid = make_frustum(f, (float)(tx0 + 8u), (float)(ty0 + 8u), (float)(tx0 + 8u), (float)(ty0 + 8u), grow);
+        // directions through the four corners of the grown block (for the facing test)
+        float cdx[4], cdy[4], cdz[4];
+        const float m = 0.0625f;
+        dir_at(f, (float)tx0 - m, (float)ty0 - m, cdx[0], cdy[0], cdz[0]);
+        dir_at(f, (float)(tx0 + 16u) + m, (float)ty0 - m, cdx[1], cdy[1], cdz[1]);
+        dir_at(f, (float)tx0 - m, (float)(ty0 + 16u) + m, cdx[2], cdy[2], cdz[2]);
+        dir_at(f, (float)(tx0 + 16u) + m, (float)(ty0 + 16u) + m, cdx[3], cdy[3], cdz[3]);
+        // bound on |direction component| over the block's samples: directions are affine in the sample position, so
+        // the corners of the grown block bound them (doubled: make_ray's own roundings are nowhere near that)
+        float dabs = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) dabs = fmaxf(dabs, fmaxf(fmaxf(fabsf(cdx[c]), fabsf(cdy[c])), fabsf(cdz[c])));
+        dabs = dabs + dabs;
+        const uint32_t nslots = nranges * kRangeMax;
+        for (uint32_t base = 0; base < nslots; base += 2u * NT) { // block-uniform trip count; two triangles per lane
+            float4 A[2], B[2], C[2];                              // and trip, all loads in flight before the first test
+            bool have[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t q = base + (uint32_t)u * NT + tid;
+                have[u] = false;
+                if (q < nslots) {
+                    const uint2 rg = S.u.t.ranges[q / kRangeMax];
+                    const uint32_t off = q % kRangeMax;
+                    if (off < rg.y) {
+                        const uint32_t k = rg.x + off;
+                        have[u] = true, A[u] = TA[k], B[u] = TB[k], C[u] = TC[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (base + (uint32_t)u * NT >= nslots) break; // block-uniform
+                bool keep = false;
+                uint32_t quads = 0;
+                const float4 a = A[u], b = B[u], c = C[u];
+                if (have[u]) {
+                    const float bx = a.x + b.x, by = a.y + b.y, bz = a.z + b.z;
+                    const float cx = a.x + c.x, cy = a.y + c.y, cz = a.z + c.z;
+                    const float lx = fminf(a.x, fminf(bx, cx)), ly = fminf(a.y, fminf(by, cy)), lz = fminf(a.z, fminf(bz, cz));
+                    const float hx = fmaxf(a.x, fmaxf(bx, cx)), hy = fmaxf(a.y, fmaxf(by, cy)), hz = fmaxf(a.z, fmaxf(bz, cz));
+                    keep = box_in_frustum(fr, lx, ly, lz, hx, hy, hz);
+                    // det = e1 . (d x e2) is linear in d and every sample direction of the block is a convex
+                    // combination of the corner directions: if det is clearly negative at all four corners the
+                    // triangle faces away from every ray of the block (cull BACK, src/invert.cpp:1334).
+                    const float nx = c.y * b.z - c.z * b.y, ny = c.z * b.x - c.x * b.z, nz = c.x * b.y - c.y * b.x;
+                    float dmax = -INFINITY, scale = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        dmax = fmaxf(dmax, (cdx[k] * nx + cdy[k] * ny) + cdz[k] * nz);
+                        scale = fmaxf(scale, (fabsf(cdx[k] * nx) + fabsf(cdy[k] * ny)) + fabsf(cdz[k] * nz));
+                    }
+                    keep = keep && !(dmax < -1e-4f * scale);
+                    if (keep) quads = box_quadrants(mid, lx, ly, lz, hx, hy, hz);
+                }
+                const uint32_t at = wave_append(&S.n_rec, keep, lane);
+                if (keep) {
+                    if (at < (uint32_t)kBlockCap) {
+                        S.u.t.rec[at][0] = a;
+                        S.u.t.rec[at][1] = b;
+                        S.u.t.rec[at][2] = c;
+                        float4 P0, P1, P2;
+                        fold_triangle(f.ox, f.oy, f.oz, dabs, a, b, c, P0, P1, P2);
+                        if (f.flags & INV_LAMBERT) P1.w = lambert_term(f, b, c); // once per record, not per shaded sample
+                        S.u.t.pre[at][0] = P0;
+                        S.u.t.pre[at][1] = P1;
+                        S.u.t.pre[at][2] = P2;
+                        S.quad[at] = quads;
+                    } else {
+                        S.overflow = 1;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (S.overflow) { // more than the LDS lists hold: every lane traverses the LBVH for its own pixel
+        for (uint32_t half = 0; half < 2u; half++) { // the stacks of two waves fit at a time
+            if ((wave >> 1) == half && valid)
+                pixel_by_traversal(f, px, py, oi, TA, TB, TC, nodes, S.u.stack + (tid & 127u), 128, ao, out);
+            __syncthreads();
+        }
+        return;
+    }
+    if (f.flags & kDebugSkipAfter2) {
+        if ((f.flags & kDebugCounts) && valid) { // list sizes instead of an image
+            if (out.depth) out.depth[oi] = __uint_as_float(S.n_ranges);
+            if (out.primid) out.primid[oi] = S.n_rec;
+        }
+        return;
+    }
+    if (stamps) t2 = __builtin_amdgcn_s_memtime();
+    // ---- phase 3: this wave's quadrant ----
+    const uint32_t nrec = S.n_rec;
+    const uint32_t pix = py * f.w + px;
+    // records whose box can touch this quadrant, as wave-uniform bit masks (64 records each)
+    uint64_t rel[kBlockCap / 64];
+#pragma unroll
+    for (int c = 0; c < kBlockCap / 64; c++) {
+        const uint32_t j = (uint32_t)c * 64u + lane;
+        rel[c] = __ballot(j < nrec && ((S.quad[j] >> wave) & 1u));
+    }
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    Hit first = miss_hit();
+    const Ray ray0 = make_ray(f, px, py, 0.5f, 0.5f);
+    for (uint32_t s = 0; s < f.spp; s++) {
+        Ray ray = ray0;
+        if (s) {
+            float sx, sy;
+            sample_offset(pix, s, f.seed, sx, sy);
+            ray = make_ray(f, px, py, sx, sy);
+        }
+        Hit best = miss_hit();
+#pragma unroll
+        for (int c = 0; c < kBlockCap / 64; c++) {
+            uint64_t todo = rel[c]; // wave-uniform
+            if (!todo) continue;
+            // cheap pass: which of the quadrant's records contain the sample (one bit per record, no divergence) ...
+            uint64_t inside = 0;
+            while (todo) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint32_t j = (uint32_t)c * 64u + i;
+                if (mt_inside_folded(ray, S.u.t.pre[j][0], S.u.t.pre[j][1], S.u.t.pre[j][2])) inside |= 1ull << i;
+            }
+            // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
+            if (f.flags & kDebugSkipExact) inside = 0; // timing experiment only
+            while (inside) {
+                const uint32_t j = (uint32_t)c * 64u + (uint32_t)__ffsll((long long)inside) - 1u;
+                inside &= inside - 1ull;
+                mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], j, best);
+            }
+        }
+        float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
+        if (best.key != kMissKey)
+            shade_hit_with(f, best, S.u.t.rec[best.slot][0], S.u.t.rec[best.slot][1], S.u.t.rec[best.slot][2],
+                           S.u.t.pre[best.slot][1].w, r, g, b);
+        sr = sr + r, sg = sg + g, sb = sb + b;
+        if (s == 0) first = best;
+    }
+    if (stamps) { // cycles per phase of wave 0 instead of an image: lanes 0..6 of the block's first row
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        if (wave == 0 && valid && out.depth) {
+            const unsigned long long r3 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long v = lane == 0 ? t1 - t0 : lane == 1 ? t2 - t1 : lane == 2 ? t3 - t2 : lane == 3 ? (unsigned long long)S.n_rec
+                                       : lane == 4 ? r3 - r0 : lane == 5 ? (t0 & 0xFFFFFFFFull) : lane == 6 ? (r0 & 0xFFFFFFFFull)
+                                       : lane == 7 ? ta - t0 : lane == 8 ? tb - ta : lane == 9 ? tc - tb : lane == 10 ? (unsigned long long)S.n_groups : 0ull;
+            out.depth[oi] = __uint_as_float((uint32_t)v);
+        }
+        return;
+    }
+    if (!valid) return;
+    const uint32_t ws = first.key != kMissKey ? first.slot : 0u;
+    finish_pixel(f, ao, out, oi, pix, ray0, first, S.u.t.rec[ws][1], S.u.t.rec[ws][2], sr, sg, sb, S.srgb);
+}
+
 // What the launcher works out for one frame of the tile kernel (host arithmetic, see plan_tile_frame).
 struct TilePlan {
-    uint32_t tiles_x, ntiles;   // 8x8 tiles of the traced rectangle
+    uint32_t block_px;          // edge of a traced block: 16 (a wave per quadrant) or 8 (the tile variants)
+    uint32_t tiles_x, ntiles;   // blocks of the traced rectangle
     uint32_t fill_blocks;       // workgroups of the fill part
     uint32_t pixel_blocks;      // 32x8 pixel blocks of the frame (fill part without 16-byte stores)
     int vec4;                   // rows and addresses allow 16-byte stores
     uint32_t row4_magic;        // floor(2^32 / chunks per row)
 };
 
-// One tile workgroup: block `tb` of the trace part of a frame's grid.
-template <int NW, bool BATCHED>
+// How a frame's traced rectangle is worked through (chosen per frame by plan_tile_frame):
+//   kBlocks   16x16 pixel blocks, a wave per quadrant (trace_block): the least arithmetic per pixel
+//   kTiles    8x8 pixel tiles whose four waves split the samples (trace_tile<4, false>): frames with four or more
+//             samples per pixel, where a wave per quadrant would carry too long a chain of samples
+//   kBatched  8x8 pixel tiles worked through in batches of leaf ranges (trace_tile<4, true>): triangles far smaller
+//             than a pixel
+enum TraceMode { kBlocks = 0, kTiles = 1, kBatched = 2 };
+
+template <int MODE>
+struct TraceLds {
+    typedef BlockLds type;
+};
+template <>
+struct TraceLds<kTiles> {
+    typedef TileLds<4, kTileCapSparse> type;
+};
+template <>
+struct TraceLds<kBatched> {
+    typedef TileLds<4, kTileCapBatched> type;
+};
+
+// One trace workgroup: block `tb` of the trace part of a frame's grid.
+template <int MODE>
 __device__ __forceinline__ void tile_block(const FrameK& f, const TilePlan& pl, uint32_t tb,
-                                           TileLds<NW, BATCHED ? kTileCapBatched : kTileCapSparse>& S,
+                                           typename TraceLds<MODE>::type& S,
                                            const float4* __restrict__ TA, const float4* __restrict__ TB,
                                            const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                            const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
                                            uint32_t ncut, const AoK& ao, const Outputs& out) {
-    const uint32_t tx0 = (f.rx0 & ~7u) + (tb % pl.tiles_x) * 8u;
-    const uint32_t ty0 = (f.ry0 & ~7u) + (tb / pl.tiles_x) * 8u;
-    if (f.nranks > 1) { // block-uniform: a tile belongs to one rank
+    constexpr uint32_t kEdge = MODE == kBlocks ? 16u : 8u;
+    const uint32_t tx0 = (f.rx0 & ~(kEdge - 1u)) + (tb % pl.tiles_x) * kEdge;
+    const uint32_t ty0 = (f.ry0 & ~(kEdge - 1u)) + (tb / pl.tiles_x) * kEdge;
+    if (f.nranks > 1) { // block-uniform: a block lies in one grid tile (their edge is a multiple of 32), so in one rank
         uint64_t dummy;
         if (!out_index(f, tx0, ty0, dummy)) return;
     }
-    trace_tile<NW, BATCHED>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+    if constexpr (MODE == kBlocks)
+        trace_block(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+    else
+        trace_tile<4, MODE == kBatched>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
 }
 
 // One workgroup of the fill part: block `fb` of pl.fill_blocks.  The fill blocks store the clear values of every
 // pixel whose 8x8 tile is not in the trace part, grid-stride: 16 bytes per lane when the row length and the buffer
 // addresses allow it (vec4), else one pixel per lane in 32x8 pixel blocks (two 128-byte lines per wave-instruction).
-template <int NW>
 __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, uint32_t fb, const Outputs& out) {
     const uint32_t tiles_x = pl.tiles_x, ntiles = pl.ntiles, fill_blocks = pl.fill_blocks;
     const uint32_t pixel_blocks = pl.pixel_blocks, row4_magic = pl.row4_magic;
     const int vec4 = pl.vec4;
     if (f.flags & kDebugSkipFill) return;
-    const uint32_t hx0 = f.rx0 & ~7u, hy0 = f.ry0 & ~7u;
-    const uint32_t hx1 = hx0 + tiles_x * 8u, hy1 = hy0 + (tiles_x ? ntiles / tiles_x : 0u) * 8u; // traced rectangle
+    const uint32_t edge = pl.block_px;
+    const uint32_t hx0 = f.rx0 & ~(edge - 1u), hy0 = f.ry0 & ~(edge - 1u);
+    const uint32_t hx1 = hx0 + tiles_x * edge, hy1 = hy0 + (tiles_x ? ntiles / tiles_x : 0u) * edge; // traced rectangle
     const uint32_t bg = background_pixel(f.flags);
     if (vec4) {
         // 16 bytes (four pixels of a row) per lane, attachment and store: 1 KiB per wave-instruction.  A wave takes runs
@@ -735,8 +1107,8 @@ __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, u
         const u32x4 c4 = {bg, bg, bg, bg}, p4 = {~0u, ~0u, ~0u, ~0u};
         const f32x4 d4 = {1.0f, 1.0f, 1.0f, 1.0f};
         const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t wave0 = __builtin_amdgcn_readfirstlane(fb * NW + (threadIdx.x >> 6));
-        const uint32_t run_stride = fill_blocks * NW * kFillRun;
+        const uint32_t wave0 = __builtin_amdgcn_readfirstlane(fb * 4u + (threadIdx.x >> 6));
+        const uint32_t run_stride = fill_blocks * 4u * kFillRun;
 #define INV_FILL_ST(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory")
 #define INV_FILL_AT(v, p, off) \
     asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "n"(off) : "memory")
@@ -796,7 +1168,6 @@ __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, u
 #undef INV_FILL_AT
         return;
     }
-    if (threadIdx.x >= 256) return; // the per-pixel path works in 32x8 pixel blocks of 256 lanes
     for (uint32_t b = fb; b < pixel_blocks; b += fill_blocks) {
         const BlockOrigin o = block_origin(f, b);
         if (!o.live) continue;
@@ -810,19 +1181,19 @@ __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, u
     }
 }
 
-// Grid = [8x8 tiles of the hit rectangle] ++ [fill blocks].
-template <int NW, bool BATCHED>
-__global__ __launch_bounds__(NW * 64, BATCHED ? 1 : 5) void k_render_tile(FrameK f, TilePlan pl,
+// Grid = [blocks of the hit rectangle] ++ [fill blocks]; workgroups of four waves.
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == kBatched ? 1 : (MODE == kTiles ? 5 : 4)) void k_render_tile(FrameK f, TilePlan pl,
                                                          const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                          const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                                          const float4* __restrict__ cut,
                                                          const float4* __restrict__ cut_groups, uint32_t ncut,
                                                          AoK ao, Outputs out) {
-    __shared__ TileLds<NW, BATCHED ? kTileCapBatched : kTileCapSparse> S;
+    __shared__ typename TraceLds<MODE>::type S;
     if (blockIdx.x < pl.ntiles)
-        tile_block<NW, BATCHED>(f, pl, blockIdx.x, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+        tile_block<MODE>(f, pl, blockIdx.x, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
     else
-        fill_part<NW>(f, pl, blockIdx.x - pl.ntiles, out);
+        fill_part(f, pl, blockIdx.x - pl.ntiles, out);
 }
 
 // Several frames in one launch (different cameras, extents and attachments, one scene).
@@ -841,22 +1212,21 @@ struct Batch {
 };
 static_assert(sizeof(Batch) <= 3072, "the batch travels in the kernel arguments");
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 5) void k_render_tile_batch(Batch b, const float4* __restrict__ TA,
+__global__ __launch_bounds__(256, 4) void k_render_tile_batch(Batch b, const float4* __restrict__ TA,
                                                                   const float4* __restrict__ TB,
                                                                   const float4* __restrict__ TC,
                                                                   const float4* __restrict__ nodes,
                                                                   const float4* __restrict__ cut,
                                                                   const float4* __restrict__ cut_groups, uint32_t ncut) {
-    __shared__ TileLds<NW, kTileCapSparse> S;
+    __shared__ BlockLds S;
     const AoK ao = {0, 0.0f, nullptr, nullptr, nullptr};
     uint32_t i = 0, first = 0; // block-uniform: frame of this block and the first block of that frame
     while (i + 1u < b.nframes && blockIdx.x >= b.block_end[i]) first = b.block_end[i], i++;
     const uint32_t local = blockIdx.x - first;
     if (local < b.fr[i].pl.ntiles)
-        tile_block<NW, false>(b.fr[i].f, b.fr[i].pl, local, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, b.fr[i].out);
+        tile_block<kBlocks>(b.fr[i].f, b.fr[i].pl, local, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, b.fr[i].out);
     else
-        fill_part<NW>(b.fr[i].f, b.fr[i].pl, local - b.fr[i].pl.ntiles, b.fr[i].out);
+        fill_part(b.fr[i].f, b.fr[i].pl, local - b.fr[i].pl.ntiles, b.fr[i].out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1013,18 +1383,8 @@ __global__ __launch_bounds__(256) void k_ao_resolve(FrameK f, AoK ao, Outputs ou
 
 } // namespace
 
-// waves per tile workgroup: 4 unless INV_TILE_WAVES says 8 or 16 (tuning knob; 4 measured fastest on the bunny)
-static int tile_waves() {
-    static const int nw = [] {
-        const char* e = std::getenv("INV_TILE_WAVES");
-        const int v = e ? std::atoi(e) : 4;
-        return (v == 8 || v == 16) ? v : 4;
-    }();
-    return nw;
-}
-
-// Grid terms of one frame of the tile kernel; `dense` says the frame needs the batched variant.
-static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Outputs& out, int nw, bool* dense) {
+// Grid terms of one frame of the tile kernel and the way its traced rectangle is worked through.
+static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch, int* mode) {
     TilePlan pl;
     if (f.rowmajor)
         pl.pixel_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
@@ -1032,20 +1392,23 @@ static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Ou
         pl.pixel_blocks = f.slots * (f.tile >> 5) * (f.tile >> 3);
     const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
     pl.vec4 = (f.w % 4u == 0) && aligned16(out.color) && aligned16(out.depth) && aligned16(out.primid);
-    uint32_t tiles_x = 0, tiles_y = 0;
-    if (f.rx1 > f.rx0 && f.ry1 > f.ry0) {
-        tiles_x = ((f.rx1 + 7u) >> 3) - (f.rx0 >> 3);
-        tiles_y = ((f.ry1 + 7u) >> 3) - (f.ry0 >> 3);
-    }
-    pl.tiles_x = tiles_x, pl.ntiles = tiles_x * tiles_y;
-    // Where triangles are much smaller than a pixel an 8x8 tile has more candidates than the record list holds:
-    // such frames take the variant that works through them in batches.
+    const bool any = f.rx1 > f.rx0 && f.ry1 > f.ry0;
+    // Where triangles are much smaller than a pixel a block has more candidates than the record list holds: such
+    // frames take the variant that works through them in batches, in 8x8 tiles.
     const double rect_px = (double)(f.rx1 - f.rx0) * (double)(f.ry1 - f.ry0);
-    *dense = pl.ntiles != 0 && (double)sc.ntri * 64.0 / rect_px > 48.0;
-    if (*dense) nw = 4;
-    const uint32_t nt = (uint32_t)nw * 64u;
-    const uint64_t fill_work = pl.vec4 ? ((f.npix >> 2) + kFillRun * nw - 1u) / (kFillRun * nw) : pl.pixel_blocks;
-    pl.fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u * 256u / nt);
+    const double per_tile = any ? (double)sc.ntri * 64.0 / rect_px : 0.0; // triangles per 8x8 pixels, if spread evenly
+    // Blocks do the least arithmetic per pixel but a wave per quadrant is a longer chain of work than a tile's four
+    // waves sharing it: a draw on its own is over sooner with tiles (12 against 21 us for the 1080p bunny), several
+    // frames sharing a launch get through sooner with blocks (4.0 against 5.1 us per frame).
+    const bool blocks = (batch || (f.flags & INV_BLOCKS)) && f.spp < 4u && per_tile <= 24.0;
+    *mode = per_tile > 48.0 ? kBatched : blocks ? kBlocks : kTiles;
+    pl.block_px = *mode == kBlocks ? 16u : 8u;
+    const uint32_t sh = *mode == kBlocks ? 4u : 3u, e1 = pl.block_px - 1u;
+    const uint32_t tiles_x = any ? ((f.rx1 + e1) >> sh) - (f.rx0 >> sh) : 0u;
+    const uint32_t tiles_y = any ? ((f.ry1 + e1) >> sh) - (f.ry0 >> sh) : 0u;
+    pl.tiles_x = tiles_x, pl.ntiles = tiles_x * tiles_y;
+    const uint64_t fill_work = pl.vec4 ? ((f.npix >> 2) + kFillRun * 4u - 1u) / (kFillRun * 4u) : pl.pixel_blocks;
+    pl.fill_blocks = (uint32_t)std::min<uint64_t>(fill_work, 2048u);
     const uint32_t row4 = std::max(1u, (f.rowmajor ? f.w : f.tile) >> 2);
     pl.row4_magic = row4 == 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / row4);
     return pl;
@@ -1067,21 +1430,19 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
                            (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, ao, out);
         return hipGetLastError();
     }
-    bool dense = false;
-    const int nw = tile_waves();
-    const TilePlan pl = plan_tile_frame(f, sc, out, nw, &dense);
-#define INV_LAUNCH_TILE(NW, B)                                                                                          \
-    hipLaunchKernelGGL((k_render_tile<NW, B>), dim3(pl.ntiles + pl.fill_blocks), dim3(NW * 64), 0, s, f, pl,            \
+    int mode = kBlocks;
+    const TilePlan pl = plan_tile_frame(f, sc, out, false, &mode);
+    if (pl.ntiles + pl.fill_blocks == 0) return hipSuccess;
+#define INV_LAUNCH_TILE(MODE)                                                                                        \
+    hipLaunchKernelGGL((k_render_tile<MODE>), dim3(pl.ntiles + pl.fill_blocks), dim3(256), 0, s, f, pl,              \
                        (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, \
                        (const float4*)sc.cut, (const float4*)sc.cut_groups, sc.ncut, ao, out)
-    if (dense)
-        INV_LAUNCH_TILE(4, true);
-    else if (nw == 8)
-        INV_LAUNCH_TILE(8, false);
-    else if (nw == 16)
-        INV_LAUNCH_TILE(16, false);
+    if (mode == kBatched)
+        INV_LAUNCH_TILE(kBatched);
+    else if (mode == kTiles)
+        INV_LAUNCH_TILE(kTiles);
     else
-        INV_LAUNCH_TILE(4, false);
+        INV_LAUNCH_TILE(kBlocks);
 #undef INV_LAUNCH_TILE
     return hipGetLastError();
 }
@@ -1089,9 +1450,9 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
 bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out) {
     if (f.npix == 0 || !sc.has_bvh || sc.height > (uint32_t)kStack) return false;
     if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE)) return false;
-    bool dense = false;
-    (void)plan_tile_frame(f, sc, out, 4, &dense);
-    return !dense;
+    int mode = kBlocks;
+    (void)plan_tile_frame(f, sc, out, true, &mode);
+    return mode == kBlocks;
 }
 
 hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
@@ -1103,17 +1464,17 @@ hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Output
     b.nframes = n;
     uint32_t blocks = 0;
     for (uint32_t i = 0; i < n; i++) {
-        bool dense = false;
+        int mode = kBlocks;
         b.fr[i].f = frames[i];
         b.fr[i].out = outs[i];
-        b.fr[i].pl = plan_tile_frame(frames[i], sc, outs[i], 4, &dense);
-        if (dense) return hipErrorInvalidValue; // the caller asks tile_batchable first
+        b.fr[i].pl = plan_tile_frame(frames[i], sc, outs[i], true, &mode);
+        if (mode != kBlocks) return hipErrorInvalidValue; // the caller asks tile_batchable first
         blocks += b.fr[i].pl.ntiles + b.fr[i].pl.fill_blocks;
         b.block_end[i] = blocks;
     }
     for (uint32_t i = n; i < kBatchMax; i++) b.block_end[i] = blocks;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_render_tile_batch<4>), dim3(blocks), dim3(256), 0, s, b, (const float4*)sc.triA,
+    hipLaunchKernelGGL(k_render_tile_batch, dim3(blocks), dim3(256), 0, s, b, (const float4*)sc.triA,
                        (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,
                        (const float4*)sc.cut_groups, sc.ncut);
     return hipGetLastError();

@@ -22,7 +22,7 @@ def bunny_scene(gpu_ctx, bunny_path):
 
 def _oracle_params(oracle, prm):
     return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays,
-                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL), prm.seed, ao_tmax=prm.ao_tmax)
+                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL | R.BLOCKS), prm.seed, ao_tmax=prm.ao_tmax)
 
 
 def test_vertex_stage_matches_oracle(oracle, bunny_scene, bunny_mesh):
@@ -33,7 +33,8 @@ def test_vertex_stage_matches_oracle(oracle, bunny_scene, bunny_mesh):
     assert np.array_equal(col.view(np.uint32), ocol.view(np.uint32))
 
 
-MODES = [0, R.BRUTE_FORCE, R.LANE_TRAVERSAL]  # tile kernel (default), brute force, per-lane stack traversal
+MODES = [0, R.BRUTE_FORCE, R.LANE_TRAVERSAL, R.BLOCKS]  # tile kernel (8x8 tiles: default), brute force, per-lane
+# stack traversal, tile kernel with 16x16 blocks (what inv_render_batch uses)
 
 
 @pytest.mark.parametrize("flags", MODES)
@@ -43,7 +44,7 @@ def test_config1_512_against_golden(bunny_scene, flags):
     assert int((got[2] != 0xFFFFFFFF).sum()) == 5651
 
 
-@pytest.mark.parametrize("mode", [0, R.LANE_TRAVERSAL])
+@pytest.mark.parametrize("mode", [0, R.LANE_TRAVERSAL, R.BLOCKS])
 def test_config2_1080_against_golden(bunny_scene, mode):
     got = bunny_scene.render(R.camera_reference(1920, 1080), R.make_params(1920, 1080, flags=mode))
     common.assert_frames_equal(got, common.golden_frame("bunny_1080_rect"), "config 2 (parity mode)")
@@ -110,7 +111,7 @@ def test_moved_camera(oracle, bunny_scene, bunny_mesh):
     cam.view[:] = view.reshape(-1).tolist()
     cam.model[:] = model.reshape(-1).tolist()
     ocam = oracle.Camera.from_buffer_copy(bytes(cam))
-    for flags in (0, R.LAMBERT, R.LANE_TRAVERSAL):
+    for flags in (0, R.LAMBERT, R.LANE_TRAVERSAL, R.BLOCKS | R.LAMBERT):
         prm = R.make_params(w, h, flags=flags)
         got = bunny_scene.render(cam, prm)
         want = oracle.render_bvh(*bunny_mesh, ocam, _oracle_params(oracle, prm))
@@ -127,7 +128,7 @@ def test_random_soup_and_degenerate_triangles(oracle, gpu_ctx):
     scene = R.Scene(gpu_ctx, mesh)
     oxyzw, oidx = oracle.parse_obj(text)
     w, h = 300, 300
-    for flags in (0, R.BRUTE_FORCE, R.LAMBERT, R.LANE_TRAVERSAL):
+    for flags in (0, R.BRUTE_FORCE, R.LAMBERT, R.LANE_TRAVERSAL, R.BLOCKS):
         prm = R.make_params(w, h, flags=flags)
         got = scene.render(R.camera_reference(w, h), prm)
         want = oracle.render_bruteforce(oxyzw, oidx, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
@@ -459,6 +460,25 @@ def test_tile_kernel_list_overflow_paths(oracle, gpu_ctx, ntri, size):
     scene.close()
 
 
+def test_few_large_overlapping_triangles_overflow_the_lists(oracle, gpu_ctx):
+    """Six hundred triangles as large as the scene, all over each other: few triangles per pixel of the rectangle (so
+    the un-batched variants are chosen) but every 8x8 tile and 16x16 block meets more of them than its record list
+    holds (128 / 256): tiles and blocks hand their pixels to the per-lane traversal."""
+    xyz, faces = objfmt.random_soup(600, seed=21, lo=(-0.01, 0.10, -0.01), hi=(0.01, 0.12, 0.01), size=0.08)
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    idx = faces.reshape(-1).astype(np.uint32)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    w, h = 320, 240
+    for flags, spp in ((0, 1), (R.BLOCKS, 1), (R.BLOCKS | R.LAMBERT, 2), (R.LAMBERT, 4)):
+        prm = R.make_params(w, h, spp=spp, seed=5, flags=flags)
+        got = scene.render(R.camera_reference(w, h), prm)
+        want = oracle.render_bvh(xyzw, idx, oracle.camera_reference(w, h), _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "large triangles flags=%d spp=%d" % (flags, spp))
+    assert (got[2] != 0xFFFFFFFF).sum() > 1500
+    scene.close()
+
+
 def test_camera_inside_the_scene(oracle, gpu_ctx):
     """Eye inside the mesh's bounding box: the projected rectangle degenerates to the whole frame, boxes straddle
     the eye plane."""
@@ -467,7 +487,7 @@ def test_camera_inside_the_scene(oracle, gpu_ctx):
     xyzw[:, :3] = xyz
     idx = faces.reshape(-1).astype(np.uint32)
     scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
-    for mode in (0, R.LANE_TRAVERSAL):
+    for mode in (0, R.LANE_TRAVERSAL, R.BLOCKS):
         prm = R.make_params(200, 150, flags=mode)
         got = scene.render(R.camera_reference(200, 150), prm)
         want = oracle.render_bruteforce(xyzw, idx, oracle.camera_reference(200, 150), _oracle_params(oracle, prm))

@@ -1,4 +1,4 @@
-"""Per-tile statistics of the tile kernel: list sizes and in-kernel cycle stamps per phase.
+"""Per-block (16x16 pixels) statistics of the tile kernel: list sizes and in-kernel cycle stamps per phase.
 
     python tools/tile_stats.py [--width 1920 --height 1080]
 
@@ -34,40 +34,46 @@ def main():
     scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))
     cam = R.camera_reference(w, h)
     _, d, p = scene.render(cam, R.make_params(w, h, flags=SKIP_AFTER2 | COUNTS))
-    nr, nrec = d.view(np.uint32)[::8, ::8], p[::8, ::8]
+    nr, nrec = d.view(np.uint32)[::16, ::16], p[::16, ::16]
     m = (nr < 100000) & (nrec < 100000)
-    print("tiles traced %d; ranges mean %.1f max %d; records mean %.1f max %d" %
+    print("blocks traced %d; ranges mean %.1f max %d; records mean %.1f max %d" %
           (m.sum(), nr[m].mean(), nr[m].max(), nrec[m].mean(), nrec[m].max()))
-    print("records histogram [0,1,8,16,32,64,128,256):", np.histogram(nrec[m], bins=[0, 1, 8, 16, 32, 64, 128, 256])[0])
+    print("records histogram [0,1,8,16,32,64,128,256]:", np.histogram(nrec[m], bins=[0, 1, 8, 16, 32, 64, 128, 257])[0])
     # stamps of the last of several launches enqueued back to back, as in a stream of frames (a launch on an idle
     # device starts its workgroups over a few microseconds, XCD after XCD)
     buf = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
-    prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT | COUNTS)
+    # STATS_FLAGS: further switches, e.g. 33554432 = no fill part (do the clear stores slow the traced blocks down?)
+    prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT | COUNTS | int(os.environ.get("STATS_FLAGS", "0")))
     for _ in range(8):
         scene.render_device(cam, prm, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr())
     stream.synchronize()
     d = buf[1].cpu().numpy().view(np.uint32).reshape(h, w)
     ys, xs = np.nonzero(m)
-    t1, t2, t3, n = (d[::8, k::8][ys, xs].astype(np.int64) for k in range(4))
+    t1, t2, t3, n = (d[::16, k::16][ys, xs].astype(np.int64) for k in range(4))
     for name, t in (("phase 1", t1), ("phase 2", t2), ("phase 3", t3), ("total", t1 + t2 + t3)):
         print("%-8s mean %6.0f  median %6.0f  max %6.0f cycles" % (name, t.mean(), np.median(t), t.max()))
-    real = d[::8, 4::8][ys, xs].astype(np.int64)  # 100 MHz ticks over the three phases
+    # phase 1 in parts (second pixel row of the block's first quadrant holds lanes 8..): start-up to the first barrier,
+    # cut groups, cut records; and the number of groups that met the block's frustum
+    pa, pb, pc, ng = d[::16, 7::16][ys, xs], d[1::16, 0::16][ys, xs], d[1::16, 1::16][ys, xs], d[1::16, 2::16][ys, xs]
+    print("phase 1 parts: start %.0f, groups %.0f, records %.0f cycles (mean); groups kept mean %.1f max %d" %
+          (pa.mean(), pb.mean(), pc.mean(), ng.mean(), ng.max()))
+    real = d[::16, 4::16][ys, xs].astype(np.int64)  # 100 MHz ticks over the three phases
     ok = real > 0
-    print("in-kernel clock: %.0f MHz (cycles / constant 100 MHz ticks, median over tiles)" %
+    print("in-kernel clock: %.0f MHz (cycles / constant 100 MHz ticks, median over blocks)" %
           np.median((t1 + t2 + t3)[ok] / real[ok] * 100.0))
-    start = d[::8, 6::8][ys, xs].astype(np.int64)
-    print("tile start spread: %.2f us; last tile end - first tile start: %.2f us" %
+    start = d[::16, 6::16][ys, xs].astype(np.int64)
+    print("block start spread: %.2f us; last block end - first block start: %.2f us" %
           ((start.max() - start.min()) / 100.0, ((start + real).max() - start.min()) / 100.0))
     rel = (start - start.min()) / 100.0
     print("start (us) percentiles 0..100:   ", " ".join("%.2f" % v for v in np.percentile(rel, range(0, 101, 10))))
     end = rel + real / 100.0
     print("end   (us) percentiles 0..100:   ", " ".join("%.2f" % v for v in np.percentile(end, range(0, 101, 10))))
     i = int(np.argmax(t1 + t2 + t3))
-    print("slowest tile: %d records, phases %d / %d / %d cycles" % (n[i], t1[i], t2[i], t3[i]))
+    print("slowest block: %d records, phases %d / %d / %d cycles" % (n[i], t1[i], t2[i], t3[i]))
     for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 256)):
         k = (n >= lo) & (n < hi)
         if k.any():
-            print("records [%3d,%3d): %4d tiles, phases %6.0f / %6.0f / %6.0f cycles" %
+            print("records [%3d,%3d): %4d blocks, phases %6.0f / %6.0f / %6.0f cycles" %
                   (lo, hi, k.sum(), t1[k].mean(), t2[k].mean(), t3[k].mean()))
 
 
