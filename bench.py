@@ -4,10 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 One step = one frame of the workload rendered through the C ABI (include/invert.h) with every input
-(triangles, LBVH) and output buffer resident in HBM.  On one GPU the frames go round-robin to --frames-in-flight
-frame slots (default 3; the reference keeps MAX_FRAMES_IN_FLIGHT = 2, src/invert.cpp:241): every frame is a whole draw
-into its slot's own attachments, and draws on different slots overlap on the GPU (a fourth slot is slower again: the
-process has four hardware queues).  With N > 1 (launched by torch.distributed.run, one
+(triangles, LBVH) and output buffer resident in HBM.  On one GPU the frames are submitted --frames-per-launch at a time
+(inv_render_batch, default 4: one launch of the tile kernel draws them all) and the submissions go round-robin to
+--frames-in-flight frame slots (default 2, the reference's MAX_FRAMES_IN_FLIGHT, src/invert.cpp:241), whose launches
+overlap on the GPU.  Every frame is a whole draw into attachments of its own (slots x frames-per-launch sets).
+Workloads with occlusion rays or four and more samples per pixel are drawn one frame per launch.  With N > 1 (launched by torch.distributed.run, one
 process per GPU) 32x32 screen tiles are dealt round-robin to the ranks, every rank renders its tiles, and the
 three attachments are gathered to rank 0 over RCCL and put together there; the same frame is rendered whatever N
 is, so scaling is "strong".  --composite sparse (default) deals out only the tiles under the scene's projected
@@ -62,7 +63,7 @@ WORKLOADS = {
 }
 
 
-def pmc_traffic(workload, world):
+def pmc_traffic(workload, world, kernel, frames_per_launch):
     """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary, or None.
 
     The counters need separate profiler passes (FETCH_SIZE and WRITE_SIZE do not fit one), so they cannot be read
@@ -76,8 +77,8 @@ def pmc_traffic(workload, world):
             doc = json.load(open(path))
         except (OSError, ValueError):
             continue
-        k = doc.get("kernels", {}).get("k_render_tile")
-        if doc.get("workload") == workload and k:
+        k = doc.get("kernels", {}).get(kernel)
+        if doc.get("workload") == workload and k and doc.get("frames_per_launch", 1) == frames_per_launch:
             best = k["hbm_bytes_per_launch"]
     return best
 
@@ -112,11 +113,14 @@ def cpu_baseline(wl, camera, budget_s=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
-                    help="one GPU: frame slots the frames are dealt to (1 = every draw on the context's stream)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
+                    help="one GPU: frame slots the submissions are dealt to")
+    ap.add_argument("--frames-per-launch", type=int, default=4, choices=range(1, 9),
+                    help="one GPU: frames per inv_render_batch submission (1 with --frames-in-flight 1: plain inv_render "
+                         "on the context's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
     ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
@@ -167,6 +171,9 @@ def main():
     sparse = world > 1 and args.composite == "sparse"
     gathered = frame = sc = None
     fif = args.frames_in_flight if world == 1 else 1  # the composite of several ranks runs on the context's stream
+    # frames per submission: occlusion rays and many samples per pixel are drawn frame by frame anyway
+    fpl = args.frames_per_launch if world == 1 and not ao_rays and spp < 4 else 1
+    slots_used = fif > 1 or fpl > 1  # else: plain inv_render on the context's stream
     if sparse:
         sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=flags, ao_rays=ao_rays)
         frame, gathered = sc.frame, sc.gathered
@@ -176,7 +183,8 @@ def main():
         prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
         npix, _ = R.tile_layout(prm)
         # one buffer, three planes (colour, depth, primitive id), 4 bytes per pixel each
-        slot_planes = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif)]
+        # attachments: one set (three planes: colour, depth, primitive id) per frame in flight
+        slot_planes = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif * fpl)]
         slot_ptr = [[p[i].data_ptr() for i in range(3)] for p in slot_planes]
         planes, ptr = slot_planes[0], slot_ptr[0]
         if world > 1 and rank == 0:
@@ -186,25 +194,39 @@ def main():
 
     # Render-kernel duration: with one GPU two HIP events per stream bracket that stream's launches of the timed
     # region (a stream holds nothing else, so their distance / launches is the average launch-to-launch time of
-    # the kernel on it; a pair of events around every launch would add about 3 us of marker latency to a 13 us
-    # kernel).  With several frames in flight that is the duration of a kernel that shares the GPU with the other
-    # slots' kernels; the frame rate is `fif` times higher.  With several GPUs the stream also carries the gather,
-    # so there a pair of events brackets every 4th render launch.
+    # the kernel on it; a pair of events around every launch would add about 3 us of marker latency).  With several
+    # slots that is the duration of a launch that shares the GPU with the other slots' launches.  With several
+    # GPUs the stream also carries the gather, so there a pair of events brackets every 4th render launch.
     every = 4
     nev = (args.steps + every - 1) // every
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    slot_streams = slot_ev = None
-    if fif > 1:
+    slot_streams = slot_ev = submissions = None
+    if slots_used:
         slot_streams = [torch.cuda.ExternalStream(ctx.frame_stream(j)) for j in range(fif)]
         slot_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(fif)]
 
+        # Submission k draws frames k*fpl .. on slot k % fif into that slot's attachment sets; the argument arrays
+        # are built once (the host work of a draw -- camera inverse, hit rectangle, grid -- stays in the call).
+        def make_submissions(nframes):
+            subs, k, i = [], 0, 0
+            while i < nframes:
+                n = min(fpl, nframes - i)
+                j = k % fif
+                subs.append((j, n, scene.make_batch([cams[(i + u) % len(cams)] if turntable else cam for u in range(n)],
+                                                    [prm] * n, [slot_ptr[j * fpl + u] for u in range(n)])))
+                i, k = i + n, k + 1
+            return subs
+
+        submissions = make_submissions(args.steps)
+        warm_submissions = make_submissions(args.warmup)
+
+    def run(subs):
+        for j, n, batch in subs:
+            scene.render_batch(batch, j)
+
     def step(i=None):
-        if fif > 1:
-            j = (i or 0) % fif
-            scene.render_in_flight(j, cams[(i or 0) % len(cams)] if turntable else cam, prm, *slot_ptr[j])
-            return
         timed = world > 1 and i is not None and i % every == 0
         if timed:
             ev0[i // every].record(stream)
@@ -234,23 +256,27 @@ def main():
             if rank == 0:
                 RD.deinterleave_on_gpu(ctx, prm0, gathered, frame)
 
-    for i in range(args.warmup):
-        step(i if fif > 1 else None)
+    if slots_used:
+        run(warm_submissions)
+    else:
+        for _ in range(args.warmup):
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev_begin.record(stream)
-    if fif > 1:
+    if slots_used:
         for j in range(fif):
             slot_ev[j][0].record(slot_streams[j])
-    for i in range(args.steps):
-        step(i)
-    if fif > 1:
+        run(submissions)
         for j in range(fif):
             slot_ev[j][1].record(slot_streams[j])
         ctx.frames_join()  # the context's stream (and ev_end on it) waits for every slot
+    else:
+        for i in range(args.steps):
+            step(i)
     ev_end.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -259,22 +285,24 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nev
-    elif fif > 1:
-        spans = [(slot_ev[j][0].elapsed_time(slot_ev[j][1]), len(range(j, args.steps, fif))) for j in range(fif)]
-        kernel_ms = sum(sp for sp, n in spans if n) / max(1, sum(n for sp, n in spans))
+    elif slots_used:  # per launch: a slot's span over the submissions it took
+        counts = [sum(1 for sub in submissions if sub[0] == j) for j in range(fif)]
+        kernel_ms = sum(slot_ev[j][0].elapsed_time(slot_ev[j][1]) for j in range(fif) if counts[j]) / max(1, sum(counts))
     else:
         kernel_ms = ev_begin.elapsed_time(ev_end) / args.steps
 
     alone_ms = None
-    if fif > 1:
-        # after the timed region: the same launches on one slot only, i.e. the kernel with the GPU to itself
+    if slots_used:
+        # after the timed region: the same submissions on one slot only, i.e. the launches with the GPU to themselves
+        # (the last frame lands where the timed region left it)
+        last_slot = submissions[-1][0]
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record(slot_streams[0])
-        for i in range(args.steps):
-            scene.render_in_flight(0, cams[i % len(cams)] if turntable else cam, prm, *slot_ptr[(args.steps - 1) % fif])
-        a1.record(slot_streams[0])
+        a0.record(slot_streams[last_slot])
+        for j, n, batch in submissions:
+            scene.render_batch(batch, last_slot)
+        a1.record(slot_streams[last_slot])
         torch.cuda.synchronize()
-        alone_ms = a0.elapsed_time(a1) / args.steps
+        alone_ms = a0.elapsed_time(a1) / len(submissions)
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -290,10 +318,12 @@ def main():
         if not torch.equal(alone, frame):
             raise SystemExit("composited frame differs from the single-GPU frame: timing rejected")
 
-    if world == 1:
-        planes = slot_planes[(args.steps - 1) % fif]  # the attachments of the last frame
-        if not turntable and not all(torch.equal(planes, p) for p in slot_planes[:min(fif, args.steps + args.warmup)]):
-            raise SystemExit("the frame slots hold different frames: timing rejected")
+    if world == 1 and slots_used:
+        j, n, _ = submissions[-1]
+        planes = slot_planes[j * fpl + n - 1]  # the attachments of the last frame
+        used = min(len(slot_planes), args.steps + args.warmup)
+        if not turntable and not all(torch.equal(planes, p) for p in slot_planes[:used]):
+            raise SystemExit("the attachment sets hold different frames: timing rejected")
     if rank == 0:
         final = frame if world > 1 else planes
         hit_pixels = int((final[2] != -1).sum()) if world == 1 or rank == 0 else 0
@@ -301,8 +331,9 @@ def main():
         value = rays_per_step * args.steps / elapsed / 1e6
         # HBM roofline of the render kernel: every pixel's colour, depth and primitive id written once,
         # triangles (48 B) and LBVH nodes (64 B) read once per frame per GPU.
-        alg_bytes = 12 * (npix if world > 1 else w * h) + scene_bytes
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        alg_bytes = 12 * (npix if world > 1 else w * h) + scene_bytes  # per frame
+        launch_bytes = alg_bytes * fpl                                 # per launch of the render kernel
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         result = {
             "metric": "Mrays/s (primary + AO) bunny @1080p, 1/2/4/8 MI355X; % HBM/VALU roofline",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -313,21 +344,22 @@ def main():
                        # 98.8 % of the primary rays miss the scene's bounds: the rate over rays of hit pixels only
                        "hit_pixel_mrays_per_s": (hit_pixels * spp + ao_rays * hit_pixels) * args.steps / elapsed / 1e6,
                        "rays_per_frame": rays_per_step, "flags": int(flags),
-                       "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile, "frames_in_flight": fif,
+                       "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0" % (args.composite, world)
                                        if world > 1 else "1 GPU")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world),
-                         "kernel": ("k_render_brute" if args.brute_force else "k_render_tile") + ("+k_ao" if ao_rays else ""),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world, "k_render_tile_batch" if fpl > 1 else "k_render_tile", fpl),
+                         "kernel": ("k_render_brute" if args.brute_force else "k_render_tile_batch" if fpl > 1
+                                    else "k_render_tile") + ("+k_ao" if ao_rays else ""),
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": launch_bytes, "frames_per_launch": fpl,
                          # the same bytes over the frame time of the whole job (kernels of different slots overlap)
                          "job": {"achieved": alg_bytes * args.steps / elapsed / 1e9,
                                  "frac": alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}},
             "cpu_baseline": None,
         }
         if alone_ms is not None:  # the same kernel when no other slot's kernel shares the GPU with it
-            result["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": alg_bytes / (alone_ms * 1e-3) / 1e9,
-                                           "frac": alg_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            result["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": launch_bytes / (alone_ms * 1e-3) / 1e9,
+                                           "frac": launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
             base, oracle_out, work = cpu_baseline(wl, cams[(args.steps - 1) % len(cams)] if turntable else cam)
@@ -342,7 +374,7 @@ def main():
             result["cpu_baseline"] = base
             # VALU side of the roofline: flops of a per-ray LBVH traversal of this frame (the oracle's test counts;
             # the tile kernel does fewer box tests than that) over the measured kernel time
-            tflops = work["flops"] / (kernel_ms * 1e-3) / 1e12
+            tflops = work["flops"] * fpl / (kernel_ms * 1e-3) / 1e12
             result["roofline"]["valu"] = {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": tflops / VALU_PEAK_TFLOPS, "oracle_traversal": work}
         print(json.dumps(result))

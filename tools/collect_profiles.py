@@ -1,0 +1,44 @@
+"""Copy one pass of tools/profile_round.sh (gpurun_out/TAG) into profiles/ under the round's names.
+
+    python tools/collect_profiles.py TAG [--prefix r01_final] [--frames-per-launch 4]
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--prefix", default="r01_final")
+    ap.add_argument("--frames-per-launch", type=int, default=4)
+    a = ap.parse_args()
+    src, dst = os.path.join(ROOT, "gpurun_out", a.tag), os.path.join(ROOT, "profiles")
+    names = {
+        "bench_default.json": "bench_bunny_1080p.json", "bench_4k_16spp.json": "bench_bunny_4k_16spp.json",
+        "bench_ao64.json": "bench_bunny_1080p_ao64.json", "phase_timing.txt": "tile_phase_timing.txt",
+        "phase_timing_3_in_flight.txt": "tile_phase_timing_3_in_flight.txt", "host_loop.txt": "host_loop.txt",
+        "tile_stats.txt": "tile_stats.txt", "pmc_phases.txt": "tile_instruction_mix.txt", "config4.txt": "config4.txt",
+        "pmc_cache.txt": "l2_valu_counters.txt", "pmc_ao.txt": "ao_instruction_mix.txt",
+    }
+    for s, d in names.items():
+        p = os.path.join(src, s)
+        if os.path.exists(p):
+            text = [ln for ln in open(p, errors="replace") if "amdgpu.ids" not in ln]  # a harmless libdrm warning
+            with open(os.path.join(dst, "%s_%s" % (a.prefix, d)), "w") as f:
+                f.writelines(text)
+        else:
+            print("missing", p)
+    tool = os.path.join(ROOT, "tools", "summarize_profiles.py")
+    subprocess.check_call([sys.executable, tool, a.prefix, os.path.join(src, "stats"), "--fetch", os.path.join(src, "fetch"),
+                           "--write", os.path.join(src, "write"), "--frames-per-launch", str(a.frames_per_launch)])
+    subprocess.check_call([sys.executable, tool, a.prefix + "_ao64", os.path.join(src, "stats_ao")])
+    shutil.rmtree(os.path.join(dst, "__pycache__"), ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,7 @@ for wl in bunny_1080p_primary_lambert_invert bunny_1080p_ao64; do
     done
 done
 for wl in bunny_1080p_primary_lambert_invert bunny_1080p_ao64; do
-    for k in k_render_tile k_ao; do
+    for k in k_render_tile_batch k_render_tile k_ao; do
         python3 tools/pmc_table.py --kernel $k "$wl/$k/L2=gpurun_out/pmc_cache/${wl}_TCC_HIT_sum" "$wl/$k/SQ=gpurun_out/pmc_cache/${wl}_SQ_BUSY_CU_CYCLES"
     done
 done | grep "=" | tee gpurun_out/pmc_cache.txt

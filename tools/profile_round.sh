@@ -8,7 +8,7 @@ R=$(pwd)
 O=$R/gpurun_out/$TAG
 rm -rf "$O" && mkdir -p "$O"
 export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --steps 200 --warmup 20"
+B="python3 $R/bench.py --no-cpu-baseline --steps 400 --warmup 40"
 timeout -k 10 200 python3 bench.py > "$O/bench_default.json"
 timeout -k 10 200 python3 bench.py --workload bunny_4k_16spp > "$O/bench_4k_16spp.json"
 timeout -k 10 200 python3 bench.py --workload bunny_1080p_ao64 > "$O/bench_ao64.json"
@@ -22,4 +22,6 @@ timeout -k 10 120 tools/micro/host_loop "$(python3 -c 'import sys; sys.path.inse
 timeout -k 10 120 python3 tools/tile_stats.py > "$O/tile_stats.txt" 2>&1
 bash tools/pmc_phases.sh > /dev/null 2>&1 && cp gpurun_out/pmc_phases.txt "$O/pmc_phases.txt"
 timeout -k 10 300 python3 tools/config4.py > "$O/config4.txt" 2>&1
+bash tools/pmc_cache.sh > /dev/null 2>&1 && cp gpurun_out/pmc_cache.txt "$O/pmc_cache.txt"
+bash tools/pmc_ao.sh > /dev/null 2>&1 && cp gpurun_out/pmc_ao.txt "$O/pmc_ao.txt"
 echo done

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert")
     ap.add_argument("--note", default="")
+    ap.add_argument("--frames-per-launch", type=int, default=1, help="frames one launch of the render kernel draws")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -64,7 +65,7 @@ def main():
             w_kb, nw = wr.get(k, (0.0, 0))
             kernels[k] = {"FETCH_SIZE_KB_avg": f_kb, "WRITE_SIZE_KB_avg": w_kb, "launches": max(nf, nw),
                           "hbm_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024)}
-        doc = {"workload": a.workload, "note": a.note,
+        doc = {"workload": a.workload, "note": a.note, "frames_per_launch": a.frames_per_launch,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; KB units; "
                          "read side doubled (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
                "kernels": kernels}
