@@ -22,7 +22,8 @@ def main():
         "bench_default.json": "bench_bunny_1080p.json", "bench_4k_16spp.json": "bench_bunny_4k_16spp.json",
         "bench_ao64.json": "bench_bunny_1080p_ao64.json", "phase_timing.txt": "tile_phase_timing.txt",
         "phase_timing_3_in_flight.txt": "tile_phase_timing_3_in_flight.txt", "host_loop.txt": "host_loop.txt",
-        "tile_stats.txt": "tile_stats.txt", "pmc_phases.txt": "tile_instruction_mix.txt", "config4.txt": "config4.txt",
+        "tile_stats.txt": "tile_stats.txt", "block_stats.txt": "block_stats.txt",
+        "phase_timing_blocks.txt": "block_phase_timing.txt", "pmc_phases.txt": "tile_instruction_mix.txt", "config4.txt": "config4.txt",
         "pmc_cache.txt": "l2_valu_counters.txt", "pmc_ao.txt": "ao_instruction_mix.txt",
     }
     for s, d in names.items():

@@ -20,6 +20,8 @@ timeout -k 10 120 python3 tools/phase_timing.py > "$O/phase_timing.txt" 2>&1
 timeout -k 10 120 python3 tools/phase_timing.py --frames-in-flight 3 > "$O/phase_timing_3_in_flight.txt" 2>&1
 timeout -k 10 120 tools/micro/host_loop "$(python3 -c 'import sys; sys.path.insert(0, "tests"); import objfmt; print(objfmt.bunny_obj_path())')" > "$O/host_loop.txt" 2>&1
 timeout -k 10 120 python3 tools/tile_stats.py > "$O/tile_stats.txt" 2>&1
+timeout -k 10 120 python3 tools/tile_stats.py --blocks > "$O/block_stats.txt" 2>&1
+timeout -k 10 120 python3 tools/phase_timing.py --flags 67 > "$O/phase_timing_blocks.txt" 2>&1
 bash tools/pmc_phases.sh > /dev/null 2>&1 && cp gpurun_out/pmc_phases.txt "$O/pmc_phases.txt"
 timeout -k 10 300 python3 tools/config4.py > "$O/config4.txt" 2>&1
 bash tools/pmc_cache.sh > /dev/null 2>&1 && cp gpurun_out/pmc_cache.txt "$O/pmc_cache.txt"
