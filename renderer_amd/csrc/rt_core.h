@@ -333,15 +333,8 @@ __device__ __forceinline__ uint32_t background_pixel(uint32_t flags) {
 
 // A pixel's attachment values are stored write-through (sc1), like the clear values: they leave the XCD's L2 as
 // they are written, so the end of the kernel has no dirty lines to write back.
-#ifndef INV_PIXEL_WT
-#define INV_PIXEL_WT 1
-#endif
 __device__ __forceinline__ void store_pixel(uint32_t* p, uint32_t v) {
-#if INV_PIXEL_WT
     asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
 }
 
 // Resolve and store one pixel whose samples were traced by this lane.  sr/sg/sb are the summed linear

@@ -1,25 +1,30 @@
 // LBVH render kernels for gfx950.
 //
-// k_render_tile (primary rays, the default).  The grid has two parts.
-//   Trace part: one workgroup of four waves per 8x8 pixel tile of the rectangle that can contain hits
-//   (the projected scene bounds).
-//     1. All 256 lanes walk the LBVH breadth-first, one node per lane, against the four side planes of
-//        the tile's frustum, starting from a precomputed cut a few levels below the root; subtrees of at
-//        most kRangeMax leaves are taken whole as a range of the sorted triangle array.  Frontier and
-//        range lists live in LDS.
-//     2. One candidate triangle per lane: its own box and its facing against the tile's frustum; the
-//        survivors' records are compacted into LDS.
-//     3. Every wave runs the Moller-Trumbore test of a quarter of the records for all 64 pixels (records
-//        come out of LDS as broadcast reads); a 64-bit LDS min per pixel picks the winning
-//        (depth, primitive) key and the lane that holds it shades and stores.
-//   If a list overflows, the first wave falls back to the per-lane stack traversal below.
-//   Fill part: 32x8 pixel blocks over the whole frame store the clear values outside the traced tiles,
-//   two full 128-byte lines per wave and attachment.
+// k_render_tile / k_render_tile_batch (primary rays, the default).  The grid of a frame has two parts.
+//   Trace part: one workgroup of four waves per pixel square of the rectangle that can contain hits (the projected
+//   scene bounds), in one of three forms chosen per frame (plan_tile_frame):
+//     8x8 tiles (a draw on its own)
+//       1. All 256 lanes walk the LBVH breadth-first, one box per lane, against the four side planes of the tile's
+//          frustum, starting from a precomputed cut a few levels below the root; subtrees of at most kRangeMax leaves
+//          are taken whole as a range of the sorted triangle array.  Frontier and range lists live in LDS.
+//       2. One candidate triangle per lane: its own box and its facing against the tile's frustum; the survivors'
+//          records are compacted into LDS.
+//       3. Every wave runs the Moller-Trumbore test of a quarter of the records for all 64 pixels (records come out of
+//          LDS as broadcast reads); a 64-bit LDS min per pixel picks the winning (depth, primitive) key and the lane
+//          that holds it shades and stores.  With four or more samples per pixel the waves split the samples instead.
+//     16x16 blocks (frames that share a launch: k_render_tile_batch; INV_BLOCKS)
+//       Steps 1 and 2 once per 256 pixels, noting for every record which 8x8 quadrants its box can touch; in step 3 a
+//       wave per quadrant walks that quadrant's records and shades and stores its own pixels.
+//     8x8 tiles, batched (triangles far smaller than a pixel)
+//       Step 3 works through the leaf ranges in batches that fit the record list.
+//   If a list overflows, the workgroup falls back to the per-lane stack traversal below.
+//   Fill part: stores the clear values outside the traced squares, 16 bytes per lane, attachment and store, a run of
+//   consecutive chunks per wave, write-through.
 //
 // k_render_bvh (INV_LANE_TRAVERSAL, and the fallback)
 //   One lane per pixel with a short stack in LDS (one column per lane).
 //
-// Both cull conservatively (boxes grown by twice the guard pad, frustum grown by 1/16 pixel, a
+// All of them cull conservatively (boxes grown by twice the guard pad, frustum grown by 1/16 pixel, a
 // slack on every comparison): every triangle that can pass the Moller-Trumbore test, whose hit point
 // must lie in the triangle's padded box, reaches that test.  The winner is the minimum
 // (depth, primitive) key, so neither the visiting order nor the superset of candidates changes a pixel.
@@ -48,10 +53,7 @@ constexpr int kRangeCap = 256;     // leaf ranges per tile
 // again and again, so it takes the larger one; the un-batched variant's smaller list leaves LDS for a fifth
 // workgroup per CU (tiles with more candidates than that fall back to the per-lane traversal).
 constexpr int kTileCapBatched = 256, kTileCapSparse = 128;
-#ifndef INV_FILL_RUN_CHUNKS
-#define INV_FILL_RUN_CHUNKS 128
-#endif
-constexpr uint32_t kFillRun = INV_FILL_RUN_CHUNKS;
+constexpr uint32_t kFillRun = 128;
 constexpr uint32_t kBatchMax = INV_BATCH_MAX; // frames per launch of the batch kernel // 16-byte chunks a wave of the fill part stores per attachment and step
 
 struct BlockMap {
@@ -364,7 +366,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool flag, ui
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// The trace part of the grid: one workgroup of NW waves per 8x8 pixel tile of the rectangle that can contain hits.
+// One workgroup of NW waves (4 in every instantiation) per 8x8 pixel tile of the rectangle that can contain hits.
 template <int NW, bool BATCHED>
 __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED ? kTileCapBatched : kTileCapSparse>& S, uint32_t tx0, uint32_t ty0,
                                            const float4* __restrict__ TA, const float4* __restrict__ TB,
