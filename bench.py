@@ -11,7 +11,9 @@ overlap on the GPU.  Every frame is a whole draw into attachments of its own (sl
 Workloads with occlusion rays or four and more samples per pixel are drawn one frame per launch.  With N > 1 (launched by torch.distributed.run, one
 process per GPU) 32x32 screen tiles are dealt round-robin to the ranks, every rank renders its tiles, and the
 three attachments are gathered to rank 0 over RCCL and put together there; the same frame is rendered whatever N
-is, so scaling is "strong".  --composite sparse (default) deals out only the tiles under the scene's projected
+is, so scaling is "strong".  The sparse composite works in groups of --composite-frames frames (default 8): one
+submission of draws and one gather per group, two sets of buffers, so that a group's gather overlaps the next
+group's draws (1: one frame per step on the context's stream).  --composite sparse (default) deals out only the tiles under the scene's projected
 bounds and rank 0 clears the rest of its frame itself; --composite dense deals out and gathers the whole frame.
 
 Rank 0 prints one JSON line with the contract fields plus
@@ -113,14 +115,16 @@ def cpu_baseline(wl, camera, budget_s=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=4000)
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
                     help="one GPU: frame slots the submissions are dealt to")
     ap.add_argument("--frames-per-launch", type=int, default=4, choices=range(1, 9),
                     help="one GPU: frames per inv_render_batch submission (1 with --frames-in-flight 1: plain inv_render "
                          "on the context's stream)")
+    ap.add_argument("--composite-frames", type=int, default=8, choices=range(1, 9),
+                    help="N > 1, sparse composite: frames per submission and per gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
     ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
@@ -174,7 +178,14 @@ def main():
     # frames per submission: occlusion rays and many samples per pixel are drawn frame by frame anyway
     fpl = args.frames_per_launch if world == 1 and not ao_rays and spp < 4 else 1
     slots_used = fif > 1 or fpl > 1  # else: plain inv_render on the context's stream
-    if sparse:
+    cb = None
+    grouped = sparse and args.composite_frames > 1
+    if grouped:
+        fpl = args.composite_frames
+        cb = RD.SparseCompositeBatch(scene, cam, w, h, rank, world, frames=fpl, sets=2, tile=tile, spp=spp, flags=flags,
+                                     ao_rays=ao_rays)
+        npix = cb.slot_elems if rank else w * h - (world - 1) * cb.slot_elems  # pixels per frame this rank writes
+    elif sparse:
         sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=flags, ao_rays=ao_rays)
         frame, gathered = sc.frame, sc.gathered
         # pixels this rank's render launch writes
@@ -226,6 +237,28 @@ def main():
         for j, n, batch in subs:
             scene.render_batch(batch, j)
 
+    # several ranks, grouped sparse composite: group g draws its frames into buffer set g % 2 and composites them
+    def make_groups(nframes):
+        return [(g % 2, min(fpl, nframes - g * fpl)) for g in range((nframes + fpl - 1) // fpl)]
+
+    def run_groups(groups):
+        for k, n in groups:
+            cb.render(k, n)
+            if args.backend == "nccl":
+                cb.composite(k, n)
+            else:  # rehearsal: the collective runs on host copies
+                ctx.frames_join()
+                if cb.slot_elems:
+                    host = RD.gather_to_rank0(cb.planes[k][:n].cpu(), rank, world)
+                    if rank == 0:
+                        cb.gathered[k][:, :n].copy_(host)
+                cb.scatter_received(k, n)
+
+    if grouped:
+        slot_streams = cb._slot_streams
+        slot_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
+        groups, warm_groups = make_groups(args.steps), make_groups(args.warmup)
+
     def step(i=None):
         timed = world > 1 and i is not None and i % every == 0
         if timed:
@@ -256,7 +289,9 @@ def main():
             if rank == 0:
                 RD.deinterleave_on_gpu(ctx, prm0, gathered, frame)
 
-    if slots_used:
+    if grouped:
+        run_groups(warm_groups)
+    elif slots_used:
         run(warm_submissions)
     else:
         for _ in range(args.warmup):
@@ -267,7 +302,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev_begin.record(stream)
-    if slots_used:
+    if grouped:
+        for j in range(2):
+            slot_ev[j][0].record(slot_streams[j])
+        run_groups(groups)
+        for j in range(2):
+            slot_ev[j][1].record(slot_streams[j])
+        ctx.frames_join()
+    elif slots_used:
         for j in range(fif):
             slot_ev[j][0].record(slot_streams[j])
         run(submissions)
@@ -283,7 +325,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:  # per submission of up to `fpl` frames: a slot's span (it also waits for the set's composite)
+        counts = [sum(1 for k, n in groups if k == j) for j in range(2)]
+        kernel_ms = sum(slot_ev[j][0].elapsed_time(slot_ev[j][1]) for j in range(2) if counts[j]) / max(1, sum(counts))
+    elif world > 1:
         kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nev
     elif slots_used:  # per launch: a slot's span over the submissions it took
         counts = [sum(1 for sub in submissions if sub[0] == j) for j in range(fif)]
@@ -315,7 +360,16 @@ def main():
         scene.render_device(cam, R.make_params(w, h, spp=spp, flags=flags, ao_rays=ao_rays), alone[0].data_ptr(), alone[1].data_ptr(),
                             alone[2].data_ptr())
         stream.synchronize()
-        if not torch.equal(alone, frame):
+        if grouped:  # every frame of the last group drawn into each set
+            last = {}
+            for k, n in warm_groups + groups:
+                last[k] = n
+            for k, n in last.items():
+                for j in range(n):
+                    if not torch.equal(alone, cb.frames[k][j]):
+                        raise SystemExit("composited frame %d of set %d differs from the single-GPU frame: timing rejected" % (j, k))
+            frame = cb.frames[groups[-1][0]][0] if groups else alone
+        elif not torch.equal(alone, frame):
             raise SystemExit("composited frame differs from the single-GPU frame: timing rejected")
 
     if world == 1 and slots_used:
@@ -345,11 +399,12 @@ def main():
                        "hit_pixel_mrays_per_s": (hit_pixels * spp + ao_rays * hit_pixels) * args.steps / elapsed / 1e6,
                        "rays_per_frame": rays_per_step, "flags": int(flags),
                        "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
-                       "parallelism": ("%s tiles %% %d + RCCL gather to rank 0" % (args.composite, world)
+                       "parallelism": ("%s tiles %% %d + RCCL gather to rank 0%s" % (
+                                           args.composite, world, ", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
                                        if world > 1 else "1 GPU")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world, "k_render_tile_batch" if fpl > 1 else "k_render_tile", fpl),
-                         "kernel": ("k_render_brute" if args.brute_force else "k_render_tile_batch" if fpl > 1
+                         "kernel": ("k_render_brute" if args.brute_force else "k_render_tile_batch" if fpl > 1 and not ao_rays and spp < 4
                                     else "k_render_tile") + ("+k_ao" if ao_rays else ""),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": launch_bytes, "frames_per_launch": fpl,
                          # the same bytes over the frame time of the whole job (kernels of different slots overlap)

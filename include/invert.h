@@ -170,7 +170,7 @@ int inv_frame_stream(inv_ctx* ctx, uint32_t slot, void** hip_stream);
  * inv_render_batch enqueues `nframes` draws of one scene at once: frame i is drawn with cams[i] and params[i] into
  * outs[i], exactly as inv_render would draw it (extents, flags and attachments may differ from frame to frame; the
  * attachments of different frames must not overlap).  Frames the tile kernel can draw directly into device
- * attachments (LBVH traversal, no occlusion rays, one rank) share launches, up to eight frames each, so that the
+ * attachments (LBVH traversal, no occlusion rays; shards of several ranks included) share launches, up to eight frames each, so that the
  * dispatch gap and the wait for a frame's slowest tiles are paid once per launch instead of once per frame;
  * anything else is drawn frame after frame.  `slot` is a frame slot (see inv_render_in_flight) or INV_CONTEXT_STREAM
  * for the context's own stream. */

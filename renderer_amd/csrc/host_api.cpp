@@ -610,7 +610,7 @@ int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const in
         int rc = prepare_frame(scene, &cams[i], &params[i], &f);
         if (rc != INV_OK) return rc;
         const Outputs o = {(uint8_t*)outs[i].color, (float*)outs[i].depth, (uint32_t*)outs[i].primid};
-        one_launch = one_launch && outs[i].on_device && params[i].ao_rays == 0 && f.nranks == 1 &&
+        one_launch = one_launch && outs[i].on_device && params[i].ao_rays == 0 &&
                      tile_batchable(f, scene->d, o);
     }
     if (!one_launch) { // the same draws one after the other (occlusion rays, host attachments, other traversals ...)

@@ -105,3 +105,86 @@ class SparseComposite:
     def composite(self):
         self.gather()
         self.scatter_received()
+
+
+class SparseCompositeBatch:
+    """The sparse composite for a stream of frames: `frames` frames per submission and per collective, and `sets`
+    sets of buffers, so that the gather of one group of frames overlaps the draws of the next.
+
+        cb = SparseCompositeBatch(scene, cam, width, height, rank, world, frames=8, flags=...)
+        for g in range(groups):
+            k = g % cb.nsets
+            cb.render(k)        # every rank: the draws of a group, one submission on frame slot k
+            cb.composite(k)     # every rank: one gather; rank 0 also copies the received tiles into cb.frames[k]
+        cb.frames[k]            # rank 0: [frames, 3, h*w] int32 planes (colour, depth bits, primitive id)
+
+    The draws of set k run on frame slot k of the scene's context; the gather and the copy run on torch's current
+    stream, which must be the context's stream.  A set's buffers are drawn into again only after its composite has
+    finished (the slot's stream waits for an event recorded behind the composite).
+    """
+
+    def __init__(self, scene: api.Scene, cam: api.Camera, width: int, height: int, rank: int, world: int,
+                 frames: int = 8, sets: int = 2, tile: int = 32, device="cuda", **params):
+        if world < 2:
+            raise ValueError("the sparse composite needs at least two ranks")
+        if not 1 <= sets <= api.MAX_FRAMES_IN_FLIGHT:
+            raise ValueError("sets must be between 1 and %d" % api.MAX_FRAMES_IN_FLIGHT)
+        self.scene, self.cam, self.rank, self.world, self.nframes, self.nsets = scene, cam, rank, world, frames, sets
+        self.width, self.height = width, height
+        flags = params.pop("flags", 0) | api.SPARSE
+        self.prm = api.make_params(width, height, tile=tile, rank=rank, nranks=world, flags=flags, **params)
+        self.prm0 = api.make_params(width, height, tile=tile, rank=0, nranks=world, flags=flags)
+        self.rect = scene.hit_rect(cam, width, height)
+        other = api.make_params(width, height, tile=tile, rank=1, nranks=world, flags=flags)
+        self.grid, self.slot_elems, _ = api.sparse_layout(other, self.rect)
+        n, F = self.slot_elems, frames
+        self.frames, self.gathered, self.planes, self._batches, self._parts = [], [], [], [], []
+        for k in range(sets):
+            if rank == 0:
+                self.frames.append(torch.empty(F, 3, width * height, dtype=torch.int32, device=device))
+                self.gathered.append(torch.empty(world, F, 3, n, dtype=torch.int32, device=device))
+                # rank 0's own part of the gather is never read; it only has to exist
+                self.planes.append(torch.zeros(F, 3, n, dtype=torch.int32, device=device))
+                outs = self.frames[k]
+            else:
+                self.frames.append(None)
+                self.gathered.append(None)
+                self.planes.append(torch.empty(F, 3, n, dtype=torch.int32, device=device))
+                outs = self.planes[k]
+            ptrs = [tuple(outs[j, p].data_ptr() for p in range(3)) for j in range(F)]
+            # batches of 1 .. F frames (the last group of a run may be short)
+            self._batches.append([scene.make_batch([cam] * m, [self.prm] * m, ptrs[:m]) for m in range(1, F + 1)])
+        self._slot_streams = [torch.cuda.ExternalStream(scene.ctx.frame_stream(k)) for k in range(sets)]
+        self._done = [torch.cuda.Event() for _ in range(sets)]
+        torch.cuda.synchronize()  # the fills above ran on torch's stream, which the slots do not wait for
+
+    def render(self, k: int, n: int | None = None):
+        """Enqueue the draws of the first n (default: all) frames of set k on frame slot k."""
+        n = self.nframes if n is None else n
+        self.scene.render_batch(self._batches[k][n - 1], slot=k)
+
+    def gather(self, k: int, n: int | None = None):
+        """The collective of set k on torch's current stream, behind the set's draws."""
+        n = self.nframes if n is None else n
+        self.scene.ctx.frames_join()
+        if self.slot_elems == 0:
+            return  # nothing on screen: rank 0's frames are already complete
+        if self.rank == 0:
+            dist.gather(self.planes[k][:n], [self.gathered[k][r, :n] for r in range(self.world)], dst=0)
+        else:
+            dist.gather(self.planes[k][:n], None, dst=0)
+
+    def scatter_received(self, k: int, n: int | None = None):
+        """Rank 0: copy the other ranks' tiles of set k into its frames (all planes of all frames in one launch);
+        every rank: let the set's slot wait for the composite before it is drawn into again."""
+        n = self.nframes if n is None else n
+        if self.rank == 0 and self.slot_elems:
+            s, F = self.slot_elems, self.nframes
+            self.scene.ctx.deinterleave_sparse(self.prm0, self.rect, self.gathered[k].data_ptr(), F * 3 * s, s, 3 * n,
+                                               self.frames[k].data_ptr(), self.width * self.height)
+        self._done[k].record()
+        self._slot_streams[k].wait_event(self._done[k])
+
+    def composite(self, k: int, n: int | None = None):
+        self.gather(k, n)
+        self.scatter_received(k, n)

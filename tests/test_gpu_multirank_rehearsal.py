@@ -20,10 +20,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(nranks, *extra):
+def _run(nranks, *extra, steps=3, warmup=1):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(nranks), "--steps", "3", "--warmup", "1", "--backend", "gloo", *extra]
+           "--gpus", str(nranks), "--steps", str(steps), "--warmup", str(warmup), "--backend", "gloo", *extra]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=170)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -39,3 +39,14 @@ def test_bench_with_several_ranks_on_one_gpu(nranks, extra):
     assert r["n_gpus"] == nranks and r["steps"] == 3 and r["scaling"] == "strong"
     assert r["value"] > 0 and r["config"]["hit_pixels"] == 25139
     assert ("dense" if "dense" in extra else "sparse") in r["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("nranks,frames,steps,warmup", [(2, 4, 19, 9), (3, 8, 20, 3), (2, 1, 3, 1)])
+def test_bench_grouped_composite_on_one_gpu(nranks, frames, steps, warmup):
+    """Groups of `frames` frames per submission and gather, alternating between two buffer sets, with short last
+    groups (steps and warm-up are not multiples of the group size); frames = 1 is the frame-by-frame composite."""
+    r = _run(nranks, "--composite-frames", str(frames), steps=steps, warmup=warmup)
+    assert r["n_gpus"] == nranks and r["steps"] == steps and r["config"]["hit_pixels"] == 25139
+    assert (("%d frames per gather" % frames) in r["config"]["parallelism"]) == (frames > 1)

@@ -210,6 +210,34 @@ def test_sparse_composite_equals_single_rank_frame(bunny_scene, gpu_ctx, mode, n
     assert n == -(-grid[2] * grid[3] // nranks) * tile * tile
 
 
+def test_batched_sparse_composite(bunny_scene, gpu_ctx):
+    """Four frames per submission and rank (inv_render_batch on shards of a sparse composite), the ranks played one
+    after another on this GPU, one inv_deinterleave_sparse over the 12 planes: every frame equals the single-rank
+    frame."""
+    import torch
+    w, h, nranks, tile, F = 1280, 720, 3, 32, 4
+    cam = R.camera_reference(w, h)
+    flags = R.LAMBERT | R.INVERT | R.SPARSE
+    full = bunny_scene.render(cam, R.make_params(w, h, flags=flags & ~R.SPARSE))
+    rect = bunny_scene.hit_rect(cam, w, h)
+    prm = [R.make_params(w, h, flags=flags, tile=tile, rank=r, nranks=nranks) for r in range(nranks)]
+    _, n, _ = R.sparse_layout(prm[1], rect)
+    frames = torch.full((F, 3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    gathered = torch.full((nranks, F, 3, n), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(nranks):
+        outs = [frames[j] if r == 0 else gathered[r, j] for j in range(F)]
+        bunny_scene.render_batch(bunny_scene.make_batch([cam] * F, [prm[r]] * F,
+                                                        [(o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()) for o in outs]))
+    gpu_ctx.deinterleave_sparse(prm[0], rect, gathered.data_ptr(), F * 3 * n, n, 3 * F, frames.data_ptr(), h * w)
+    gpu_ctx.synchronize()
+    host = frames.cpu().numpy()
+    for j in range(F):
+        got = (host[j, 0].view(np.uint8).reshape(h, w, 4), host[j, 1].view(np.float32).reshape(h, w),
+               host[j, 2].view(np.uint32).reshape(h, w))
+        common.assert_frames_equal(got, full, "batched sparse composite, frame %d" % j)
+
+
 def test_sparse_composite_with_jitter_and_occlusion(bunny_scene, gpu_ctx):
     w, h = 640, 360
     cam = R.camera_reference(w, h)
