@@ -102,6 +102,12 @@ int inv_mesh_from_arrays(const float* xyzw, uint32_t nv, const uint32_t* idx, ui
 int inv_mesh_counts(const inv_mesh* mesh, uint32_t* nv, uint32_t* nidx);
 const float* inv_mesh_vertices(const inv_mesh* mesh);  /* Obj::vertexData, nv*4 floats */
 const uint32_t* inv_mesh_indices(const inv_mesh* mesh); /* Obj::indexData, nidx values, 0-based */
+/* Moves the mesh's arrays into page-locked host memory, so that the uploads of later scene builds are DMA straight
+ * out of them (the staging buffer transferData keeps host-visible for its transfer queue, src/invert.cpp:993-1082, and
+ * its TODO about keeping staging buffers mapped, src/invert.cpp:992).  Optional: builds from an unpinned mesh copy
+ * through the runtime's own staging.  Needs a HIP device (INV_ERR_NO_DEVICE otherwise); pointers handed out by
+ * inv_mesh_vertices / inv_mesh_indices before the call are invalid after it. */
+int inv_mesh_pin(inv_mesh* mesh);
 int inv_mesh_destroy(inv_mesh* mesh);                   /* Obj::~Obj (src/invert.cpp:33-39) */
 
 /* ---- camera: updateUniformBuffer ------------------------------------------------------------------------- */
@@ -114,7 +120,8 @@ int inv_camera_reference(uint32_t width, uint32_t height, inv_camera* cam);
 int inv_camera_turntable(uint32_t width, uint32_t height, float elapsed_seconds, inv_camera* cam);
 
 /* ---- scene: vertex/index buffers + acceleration structure -------------------------------------------------- */
-/* Uploads the mesh (src/invert.cpp:1136-1140, 1161-1164), assembles triangle k from indices 3k..3k+2
+/* Uploads the mesh (src/invert.cpp:1136-1140, 1161-1164; on a transfer stream of the context's own, as transferData
+ * uses the transfer queue, src/invert.cpp:993-1082), assembles triangle k from indices 3k..3k+2
  * (VK_PRIMITIVE_TOPOLOGY_TRIANGLE_LIST, src/invert.cpp:1307-1310) into the HBM triangle arrays and builds the
  * LBVH over them on the GPU.  The mesh may be destroyed afterwards. */
 int inv_scene_build(inv_ctx* ctx, const inv_mesh* mesh, inv_scene** out);

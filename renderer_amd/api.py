@@ -24,7 +24,7 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEV
 SYMBOLS = (
     "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize",
     "inv_mesh_load_obj", "inv_mesh_load_obj_general", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
-    "inv_mesh_indices", "inv_mesh_destroy",
+    "inv_mesh_indices", "inv_mesh_pin", "inv_mesh_destroy",
     "inv_camera_reference", "inv_camera_turntable",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
     "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
@@ -90,6 +90,7 @@ def lib():
     L.inv_mesh_vertices.restype = C.POINTER(C.c_float)
     L.inv_mesh_indices.argtypes = [vp]
     L.inv_mesh_indices.restype = u32p
+    L.inv_mesh_pin.argtypes = [vp]
     L.inv_mesh_destroy.argtypes = [vp]
     L.inv_camera_reference.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera)]
     L.inv_camera_turntable.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(Camera)]
@@ -180,6 +181,11 @@ class Mesh:
         nv, nidx = C.c_uint32(), C.c_uint32()
         _chk(lib().inv_mesh_counts(self._h, C.byref(nv), C.byref(nidx)))
         return nv.value, nidx.value
+
+    def pin(self) -> "Mesh":
+        """Move the arrays into page-locked host memory: scene builds then upload by DMA straight out of them."""
+        _chk(lib().inv_mesh_pin(self._h))
+        return self
 
     @property
     def vertices(self) -> np.ndarray:

@@ -43,6 +43,9 @@ struct inv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // uploads of a scene build run on a stream of their own (created on first use), the build waits for its event
+    hipStream_t transfer = nullptr;
+    hipEvent_t uploaded = nullptr;
     // frame slots (created on first use): a stream each, and an event the join records on it
     hipStream_t flight[INV_MAX_FRAMES_IN_FLIGHT] = {};
     hipEvent_t flight_done[INV_MAX_FRAMES_IN_FLIGHT] = {};
@@ -51,6 +54,14 @@ struct inv_ctx {
 struct inv_mesh {
     std::vector<float> xyzw;
     std::vector<uint32_t> idx;
+    // after inv_mesh_pin: the same arrays in page-locked host memory (the vectors are then empty)
+    float* pinned_xyzw = nullptr;
+    uint32_t* pinned_idx = nullptr;
+    size_t nxyzw = 0, nidx = 0; // element counts of the pinned arrays
+    const float* vertices() const { return pinned_xyzw ? pinned_xyzw : xyzw.data(); }
+    const uint32_t* indices() const { return pinned_idx ? pinned_idx : idx.data(); }
+    size_t vertex_floats() const { return pinned_xyzw ? nxyzw : xyzw.size(); }
+    size_t index_count() const { return pinned_idx ? nidx : idx.size(); }
 };
 
 // What one draw needs beside the caller's attachments.  Draws on different streams must not share it, so a scene
@@ -185,6 +196,8 @@ int inv_ctx_destroy(inv_ctx* ctx) {
         if (ctx->flight[i]) (void)hipStreamSynchronize(ctx->flight[i]), (void)hipStreamDestroy(ctx->flight[i]);
         if (ctx->flight_done[i]) (void)hipEventDestroy(ctx->flight_done[i]);
     }
+    if (ctx->transfer) (void)hipStreamSynchronize(ctx->transfer), (void)hipStreamDestroy(ctx->transfer);
+    if (ctx->uploaded) (void)hipEventDestroy(ctx->uploaded);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return INV_OK;
@@ -264,15 +277,42 @@ INV_CATCH("inv_mesh_from_arrays")
 
 int inv_mesh_counts(const inv_mesh* mesh, uint32_t* nv, uint32_t* nidx) {
     if (!mesh) return fail(INV_ERR_ARG, "inv_mesh_counts: mesh is null");
-    if (nv) *nv = (uint32_t)(mesh->xyzw.size() / 4);
-    if (nidx) *nidx = (uint32_t)mesh->idx.size();
+    if (nv) *nv = (uint32_t)(mesh->vertex_floats() / 4);
+    if (nidx) *nidx = (uint32_t)mesh->index_count();
     return INV_OK;
 }
 
-const float* inv_mesh_vertices(const inv_mesh* mesh) { return mesh ? mesh->xyzw.data() : nullptr; }
-const uint32_t* inv_mesh_indices(const inv_mesh* mesh) { return mesh ? mesh->idx.data() : nullptr; }
+const float* inv_mesh_vertices(const inv_mesh* mesh) { return mesh ? mesh->vertices() : nullptr; }
+const uint32_t* inv_mesh_indices(const inv_mesh* mesh) { return mesh ? mesh->indices() : nullptr; }
+
+int inv_mesh_pin(inv_mesh* mesh) {
+    if (!mesh) return fail(INV_ERR_ARG, "inv_mesh_pin: mesh is null");
+    if (mesh->pinned_xyzw || mesh->pinned_idx) return INV_OK; // already pinned
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(INV_ERR_NO_DEVICE, "inv_mesh_pin: page-locked memory needs a HIP device");
+    const size_t nx = mesh->xyzw.size(), ni = mesh->idx.size();
+    float* px = nullptr;
+    uint32_t* pi = nullptr;
+    hipError_t e = hipHostMalloc((void**)&px, std::max<size_t>(nx * 4, 16), hipHostMallocDefault);
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(vertices)");
+    e = hipHostMalloc((void**)&pi, std::max<size_t>(ni * 4, 16), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipHostFree(px);
+        return hip_fail(e, "hipHostMalloc(indices)");
+    }
+    if (nx) std::memcpy(px, mesh->xyzw.data(), nx * 4);
+    if (ni) std::memcpy(pi, mesh->idx.data(), ni * 4);
+    mesh->pinned_xyzw = px, mesh->pinned_idx = pi, mesh->nxyzw = nx, mesh->nidx = ni;
+    std::vector<float>().swap(mesh->xyzw);
+    std::vector<uint32_t>().swap(mesh->idx);
+    return INV_OK;
+}
 
 int inv_mesh_destroy(inv_mesh* mesh) {
+    if (!mesh) return INV_OK;
+    if (mesh->pinned_xyzw) (void)hipHostFree(mesh->pinned_xyzw);
+    if (mesh->pinned_idx) (void)hipHostFree(mesh->pinned_idx);
     delete mesh;
     return INV_OK;
 }
@@ -300,8 +340,10 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     *out = nullptr;
     if (!ctx || !mesh) return fail(INV_ERR_ARG, "inv_scene_build: ctx or mesh is null");
     if (ninst == 0) return fail(INV_ERR_ARG, "inv_scene_build: ninst must be at least 1");
-    const uint32_t nv = (uint32_t)(mesh->xyzw.size() / 4);
-    const uint32_t base_ntri = (uint32_t)(mesh->idx.size() / 3);
+    const uint32_t nv = (uint32_t)(mesh->vertex_floats() / 4);
+    const uint32_t base_ntri = (uint32_t)(mesh->index_count() / 3);
+    const float* hv = mesh->vertices();
+    const uint32_t* hi = mesh->indices();
     const uint64_t ntri64 = (uint64_t)base_ntri * ninst;
     if (ntri64 >= 0x7FFFFFFFull) return fail(INV_ERR_ARG, "inv_scene_build: more than 2^31 triangles");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -311,16 +353,57 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     DeviceScene& d = s->d;
     d.nv = nv;
     d.ntri = (uint32_t)ntri64;
-    // Largest |coordinate| the rays can meet (feeds the guard pad) and the bounding box of the vertices as stored,
-    // over all instances.  Rounding is monotonic, so the extremes of fl(v + t) over vertices and instances are
+    // Two device allocations per build: what the scene keeps, and what only the build needs.
+    const size_t tri_bytes = Arena::aligned((size_t)d.ntri * 16);
+    const bool tree = d.ntri >= 2;
+    Arena keep, scratch;
+    keep.size = Arena::aligned((size_t)nv * 16) + Arena::aligned((size_t)base_ntri * 12) + 3 * tri_bytes +
+                lbvh_keep_bytes(d.ntri) + 256;
+    scratch.size = (tree ? 3 * tri_bytes + lbvh_scratch_bytes(d.ntri) : 0) + Arena::aligned((size_t)ninst * 12) + 256;
+    int rc = INV_OK;
+    hipError_t e = hipSuccess;
+    auto bail = [&](hipError_t err, const char* what) {
+        rc = hip_fail(err, what);
+        if (ctx->transfer) (void)hipStreamSynchronize(ctx->transfer);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (scratch.base) (void)hipFree(scratch.base);
+        free_device_scene(d);
+        delete s;
+        return rc;
+    };
+    if ((e = hipMalloc((void**)&keep.base, keep.size)) != hipSuccess) return bail(e, "hipMalloc(scene)");
+    d.arena = keep.base;
+    if ((e = hipMalloc((void**)&scratch.base, scratch.size)) != hipSuccess) return bail(e, "hipMalloc(build scratch)");
+    // The Obj arrays (src/invert.cpp:1136-1140, 1161-1164) go up on the context's transfer stream, the way
+    // transferData uses a dedicated transfer queue (src/invert.cpp:993-1082); the build on the context's stream waits
+    // for the event behind them.  From a pinned mesh (inv_mesh_pin) the copies are DMA straight out of the arrays
+    // and the calls return at once.
+    if (!ctx->transfer) {
+        if ((e = hipStreamCreateWithFlags(&ctx->transfer, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreateWithFlags(transfer)");
+        if ((e = hipEventCreateWithFlags(&ctx->uploaded, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreateWithFlags");
+    }
+    if (nv) {
+        d.xyzw = keep.take<float>((size_t)nv * 16);
+        if ((e = hipMemcpyAsync(d.xyzw, hv, (size_t)nv * 16, hipMemcpyHostToDevice, ctx->transfer)) != hipSuccess)
+            return bail(e, "hipMemcpyAsync(vertices)");
+    }
+    if (base_ntri) {
+        d.idx = keep.take<uint32_t>((size_t)base_ntri * 12);
+        if ((e = hipMemcpyAsync(d.idx, hi, (size_t)base_ntri * 12, hipMemcpyHostToDevice, ctx->transfer)) != hipSuccess)
+            return bail(e, "hipMemcpyAsync(indices)");
+    }
+    if ((e = hipEventRecord(ctx->uploaded, ctx->transfer)) != hipSuccess) return bail(e, "hipEventRecord(upload)");
+    if ((e = hipStreamWaitEvent(ctx->stream, ctx->uploaded, 0)) != hipSuccess) return bail(e, "hipStreamWaitEvent(upload)");
+    // While the uploads run (from a pinned mesh they are DMA in the background): largest |coordinate| the rays can
+    // meet (feeds the guard pad) and the bounding box of the vertices as stored, over all instances.  Rounding is monotonic, so the extremes of fl(v + t) over vertices and instances are
     // fl(vmin + tmin) and fl(vmax + tmax) per axis: no need to visit every pair.
     float max_abs = 0.0f;
     if (nv) {
         float vlo[3] = {INFINITY, INFINITY, INFINITY}, vhi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (uint32_t i = 0; i < nv; i++)
             for (int c = 0; c < 3; c++) {
-                const float v = mesh->xyzw[(size_t)i * 4 + c];
-                vlo[c] = std::fmin(vlo[c], v), vhi[c] = std::fmax(vhi[c], v);
+                const float v = hv[(size_t)i * 4 + c];
+                vlo[c] = v < vlo[c] ? v : vlo[c], vhi[c] = v > vhi[c] ? v : vhi[c]; // a NaN is skipped, as by fmin/fmax
             }
         float lo[3], hi[3];
         for (int c = 0; c < 3; c++) {
@@ -339,37 +422,6 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         s->vertex_diag = std::sqrt((ex * ex + ey * ey) + ez * ez);
     }
     s->max_abs = max_abs;
-    // Two device allocations per build: what the scene keeps, and what only the build needs.
-    const size_t tri_bytes = Arena::aligned((size_t)d.ntri * 16);
-    const bool tree = d.ntri >= 2;
-    Arena keep, scratch;
-    keep.size = Arena::aligned((size_t)nv * 16) + Arena::aligned((size_t)base_ntri * 12) + 3 * tri_bytes +
-                lbvh_keep_bytes(d.ntri) + 256;
-    scratch.size = (tree ? 3 * tri_bytes + lbvh_scratch_bytes(d.ntri) : 0) + Arena::aligned((size_t)ninst * 12) + 256;
-    int rc = INV_OK;
-    hipError_t e = hipSuccess;
-    auto bail = [&](hipError_t err, const char* what) {
-        rc = hip_fail(err, what);
-        (void)hipStreamSynchronize(ctx->stream);
-        if (scratch.base) (void)hipFree(scratch.base);
-        free_device_scene(d);
-        delete s;
-        return rc;
-    };
-    if ((e = hipMalloc((void**)&keep.base, keep.size)) != hipSuccess) return bail(e, "hipMalloc(scene)");
-    d.arena = keep.base;
-    if ((e = hipMalloc((void**)&scratch.base, scratch.size)) != hipSuccess) return bail(e, "hipMalloc(build scratch)");
-    if (nv) {
-        d.xyzw = keep.take<float>((size_t)nv * 16);
-        // host-visible copy of the Obj arrays (src/invert.cpp:1136-1140, 1161-1164)
-        if ((e = hipMemcpyAsync(d.xyzw, mesh->xyzw.data(), (size_t)nv * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return bail(e, "hipMemcpyAsync(vertices)");
-    }
-    if (base_ntri) {
-        d.idx = keep.take<uint32_t>((size_t)base_ntri * 12);
-        if ((e = hipMemcpyAsync(d.idx, mesh->idx.data(), (size_t)base_ntri * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return bail(e, "hipMemcpyAsync(indices)");
-    }
     if (d.ntri) {
         d.triA = keep.take<float>((size_t)d.ntri * 16);
         d.triB = keep.take<float>((size_t)d.ntri * 16);

@@ -421,6 +421,25 @@ def test_frames_join_orders_the_context_stream(bunny_path):
     ctx.close()
 
 
+def test_pinned_mesh_builds_the_same_scene(gpu_ctx, bunny_path):
+    """inv_mesh_pin: the arrays move to page-locked memory (accessors keep working, pinning twice is harmless) and a
+    scene built from them draws the same frame; so does a second build from the same pinned mesh."""
+    mesh = R.Mesh.load_obj(bunny_path)
+    v0, i0 = mesh.vertices, mesh.indices
+    mesh.pin().pin()
+    assert mesh.counts() == (2503, 14904)
+    assert np.array_equal(mesh.vertices.view(np.uint32)[:, :3], v0.view(np.uint32)[:, :3]) and np.array_equal(mesh.indices, i0)
+    for _ in range(2):
+        scene = R.Scene(gpu_ctx, mesh)
+        got = scene.render(R.camera_reference(512, 512), R.make_params(512, 512))
+        common.assert_frames_equal(got, common.golden_frame("bunny_512"), "pinned mesh")
+        scene.close()
+    empty = R.Mesh.from_arrays(np.zeros((0, 4), np.float32), np.zeros(0, np.uint32)).pin()
+    assert empty.counts() == (0, 0)
+    mesh.close()
+    empty.close()
+
+
 def test_errors(bunny_scene):
     cam = R.camera_reference(64, 64)
     with pytest.raises(R.InvertError):

@@ -162,6 +162,11 @@ def test_no_gpu_is_a_loud_error():
     with pytest.raises(R.InvertError) as e:
         R.Context(0)
     assert e.value.code == api.ERR_NO_DEVICE
+    mesh = R.Mesh.from_arrays(np.zeros((3, 4), np.float32), np.array([0, 1, 2], np.uint32))
+    with pytest.raises(R.InvertError) as e:
+        mesh.pin()  # page-locked memory needs a device; the mesh stays usable as it is
+    assert e.value.code == api.ERR_NO_DEVICE
+    assert mesh.counts() == (3, 3) and mesh.indices.tolist() == [0, 1, 2]
 
 
 def test_product_does_not_reference_the_oracle():
