@@ -120,8 +120,7 @@ int inv_camera_reference(uint32_t width, uint32_t height, inv_camera* cam);
 int inv_camera_turntable(uint32_t width, uint32_t height, float elapsed_seconds, inv_camera* cam);
 
 /* ---- scene: vertex/index buffers + acceleration structure -------------------------------------------------- */
-/* Uploads the mesh (src/invert.cpp:1136-1140, 1161-1164; on a transfer stream of the context's own, as transferData
- * uses the transfer queue, src/invert.cpp:993-1082), assembles triangle k from indices 3k..3k+2
+/* Uploads the mesh (src/invert.cpp:1136-1140, 1161-1164), assembles triangle k from indices 3k..3k+2
  * (VK_PRIMITIVE_TOPOLOGY_TRIANGLE_LIST, src/invert.cpp:1307-1310) into the HBM triangle arrays and builds the
  * LBVH over them on the GPU.  The mesh may be destroyed afterwards. */
 int inv_scene_build(inv_ctx* ctx, const inv_mesh* mesh, inv_scene** out);

@@ -43,9 +43,7 @@ struct inv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // uploads of a scene build run on a stream of their own (created on first use), the build waits for its event
-    hipStream_t transfer = nullptr;
-    hipEvent_t uploaded = nullptr;
+
     // frame slots (created on first use): a stream each, and an event the join records on it
     hipStream_t flight[INV_MAX_FRAMES_IN_FLIGHT] = {};
     hipEvent_t flight_done[INV_MAX_FRAMES_IN_FLIGHT] = {};
@@ -196,8 +194,6 @@ int inv_ctx_destroy(inv_ctx* ctx) {
         if (ctx->flight[i]) (void)hipStreamSynchronize(ctx->flight[i]), (void)hipStreamDestroy(ctx->flight[i]);
         if (ctx->flight_done[i]) (void)hipEventDestroy(ctx->flight_done[i]);
     }
-    if (ctx->transfer) (void)hipStreamSynchronize(ctx->transfer), (void)hipStreamDestroy(ctx->transfer);
-    if (ctx->uploaded) (void)hipEventDestroy(ctx->uploaded);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return INV_OK;
@@ -364,7 +360,6 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     hipError_t e = hipSuccess;
     auto bail = [&](hipError_t err, const char* what) {
         rc = hip_fail(err, what);
-        if (ctx->transfer) (void)hipStreamSynchronize(ctx->transfer);
         (void)hipStreamSynchronize(ctx->stream);
         if (scratch.base) (void)hipFree(scratch.base);
         free_device_scene(d);
@@ -374,26 +369,21 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     if ((e = hipMalloc((void**)&keep.base, keep.size)) != hipSuccess) return bail(e, "hipMalloc(scene)");
     d.arena = keep.base;
     if ((e = hipMalloc((void**)&scratch.base, scratch.size)) != hipSuccess) return bail(e, "hipMalloc(build scratch)");
-    // The Obj arrays (src/invert.cpp:1136-1140, 1161-1164) go up on the context's transfer stream, the way
-    // transferData uses a dedicated transfer queue (src/invert.cpp:993-1082); the build on the context's stream waits
-    // for the event behind them.  From a pinned mesh (inv_mesh_pin) the copies are DMA straight out of the arrays
-    // and the calls return at once.
-    if (!ctx->transfer) {
-        if ((e = hipStreamCreateWithFlags(&ctx->transfer, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreateWithFlags(transfer)");
-        if ((e = hipEventCreateWithFlags(&ctx->uploaded, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreateWithFlags");
-    }
+    // The Obj arrays go up first (src/invert.cpp:1136-1140, 1161-1164).  From a pinned mesh (inv_mesh_pin: the
+    // host-visible staging buffer of transferData, src/invert.cpp:993-1082) the copies are DMA straight out of the
+    // arrays and these calls return at once; the context's stream keeps them in order with the build's kernels.
+    // (A stream of its own for the copies was tried: it brought nothing more and took one of the process's four
+    // hardware queues away from the frame slots.)
     if (nv) {
         d.xyzw = keep.take<float>((size_t)nv * 16);
-        if ((e = hipMemcpyAsync(d.xyzw, hv, (size_t)nv * 16, hipMemcpyHostToDevice, ctx->transfer)) != hipSuccess)
+        if ((e = hipMemcpyAsync(d.xyzw, hv, (size_t)nv * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return bail(e, "hipMemcpyAsync(vertices)");
     }
     if (base_ntri) {
         d.idx = keep.take<uint32_t>((size_t)base_ntri * 12);
-        if ((e = hipMemcpyAsync(d.idx, hi, (size_t)base_ntri * 12, hipMemcpyHostToDevice, ctx->transfer)) != hipSuccess)
+        if ((e = hipMemcpyAsync(d.idx, hi, (size_t)base_ntri * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
             return bail(e, "hipMemcpyAsync(indices)");
     }
-    if ((e = hipEventRecord(ctx->uploaded, ctx->transfer)) != hipSuccess) return bail(e, "hipEventRecord(upload)");
-    if ((e = hipStreamWaitEvent(ctx->stream, ctx->uploaded, 0)) != hipSuccess) return bail(e, "hipStreamWaitEvent(upload)");
     // While the uploads run (from a pinned mesh they are DMA in the background): largest |coordinate| the rays can
     // meet (feeds the guard pad) and the bounding box of the vertices as stored, over all instances.  Rounding is monotonic, so the extremes of fl(v + t) over vertices and instances are
     // fl(vmin + tmin) and fl(vmax + tmax) per axis: no need to visit every pair.

@@ -1222,8 +1222,16 @@ __global__ __launch_bounds__(256, 4) void k_render_tile_batch(Batch b, const flo
                                                                   const float4* __restrict__ cut_groups, uint32_t ncut) {
     __shared__ BlockLds S;
     const AoK ao = {0, 0.0f, nullptr, nullptr, nullptr};
-    uint32_t i = 0, first = 0; // block-uniform: frame of this block and the first block of that frame
-    while (i + 1u < b.nframes && blockIdx.x >= b.block_end[i]) first = b.block_end[i], i++;
+    // block-uniform: frame of this block and the first block of that frame.  The running sums are read in one go and
+    // compared without branches (entries past the last frame hold the grid size, which no block index reaches).
+    uint32_t i = 0, first = 0;
+#pragma unroll
+    for (uint32_t k = 0; k + 1u < kBatchMax; k++) {
+        const uint32_t e = b.block_end[k];
+        const bool past = blockIdx.x >= e;
+        i += past ? 1u : 0u;
+        first = past ? e : first;
+    }
     const uint32_t local = blockIdx.x - first;
     if (local < b.fr[i].pl.ntiles)
         tile_block<kBlocks>(b.fr[i].f, b.fr[i].pl, local, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, b.fr[i].out);
