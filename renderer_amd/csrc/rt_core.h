@@ -110,6 +110,40 @@ __device__ __forceinline__ bool mt_inside_folded(const Ray& r, const float4& P0,
     return (det > -e) & !(un < -e) & !(un > hi) & !(vn < 0.0f) & !(un + vn > hi);
 }
 
+// The same decision for two records at once in packed fp32 arithmetic.  The records' folded terms are stored
+// interleaved (record a in the low, record b in the high half of every pair of floats):
+//   q0 = (P0.x, P0.y)   q1 = (P0.z, P1.x)   q2 = (P1.y, P1.z)   q3 = (P2.x, P2.y)   q4 = (P2.z, eps)
+// Fused multiply-adds and another summation order than mt_test's: every value differs from mt_test's by rounding only,
+// so all comparisons are widened by eps (pair_eps below bounds the products of all three dot products), and the
+// five conditions become one minimum.  A NaN is dropped by the minimum (conservative).  Bit 0: record a, bit 1: b.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float pair_eps(float ox, float oy, float oz, float dmax, const float4& A, const float4& B,
+                                          const float4& C) {
+    const float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
+    const float c1 = (fabsf(C.x) + fabsf(C.y)) + fabsf(C.z);
+    const float b1 = (fabsf(B.x) + fabsf(B.y)) + fabsf(B.z), t1 = (fabsf(tx) + fabsf(ty)) + fabsf(tz);
+    // det: products below dmax*c1*b1, un: dmax*c1*t1, vn: dmax*t1*b1; a dozen roundings of 2^-24 each
+    return 0x1p-18f * dmax * fmaxf(c1 * fmaxf(b1, t1), t1 * b1);
+}
+
+__device__ __forceinline__ uint32_t mt_inside_pair(const Ray& r, const float4& q0, const float4& q1, const float4& q2,
+                                                   const float4& q3, const float4& q4) {
+    const pk2 dx = {r.dx, r.dx}, dy = {r.dy, r.dy}, dz = {r.dz, r.dz};
+    const pk2 p0x = {q0.x, q0.y}, p0y = {q0.z, q0.w}, p0z = {q1.x, q1.y};
+    const pk2 p1x = {q1.z, q1.w}, p1y = {q2.x, q2.y}, p1z = {q2.z, q2.w};
+    const pk2 p2x = {q3.x, q3.y}, p2y = {q3.z, q3.w}, p2z = {q4.x, q4.y};
+    const pk2 e = {q4.z, q4.w};
+    const pk2 det = __builtin_elementwise_fma(dx, p0x, __builtin_elementwise_fma(dy, p0y, dz * p0z));
+    const pk2 un = __builtin_elementwise_fma(dx, p1x, __builtin_elementwise_fma(dy, p1y, dz * p1z));
+    const pk2 vn = __builtin_elementwise_fma(dx, p2x, __builtin_elementwise_fma(dy, p2y, dz * p2z));
+    const pk2 e2 = e + e, hi = det + e2;
+    const pk2 t1 = det + e, t2 = un + e, t3 = hi - un, t4 = vn + e, t5 = (hi + e) - (un + vn);
+    const float ma = fminf(fminf(fminf(t1.x, t2.x), fminf(t3.x, t4.x)), t5.x);
+    const float mb = fminf(fminf(fminf(t1.y, t2.y), fminf(t3.y, t4.y)), t5.y);
+    return (uint32_t)!(ma < 0.0f) | ((uint32_t)!(mb < 0.0f) << 1);
+}
+
 // Triangle record: three float4
 //   A = (v0.xyz, primitive id bits)   B = (e1.xyz, z of vertex 1)   C = (e2.xyz, z of vertex 2)
 // with e1 = v1 - v0, e2 = v2 - v0 rounded once at assembly.

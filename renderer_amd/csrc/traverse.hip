@@ -711,12 +711,14 @@ struct BlockLds {
             uint32_t frontier[2][kFrontierCap];
             uint2 ranges[kRangeCap];      // (first sorted triangle, count <= kRangeMax)
             float4 rec[kBlockCap][3];     // candidate records A, B, C that survived the per-triangle test
-            float4 pre[kBlockCap][3];     // their folded terms for the cheap inside test (fold_triangle)
+            float4 pre2[kBlockCap / 2][5]; // folded terms of the cheap inside test, two records interleaved
+                                           // (mt_inside_pair)
         } t;
         uint32_t stack[kStack * 128]; // fallback: per-lane traversal, one column per lane, two waves at a time
     } u;
     float srgb[256];            // copy of the sRGB threshold table
     uint32_t quad[kBlockCap];   // per record: the quadrants (bit = wave) its box can touch
+    float lambert[kBlockCap];   // per record: Lambert factor of the triangle
     uint32_t groups[kCutCap / kCutGroup]; // cut groups whose box meets the block's frustum
     uint32_t n_groups;
     uint32_t n_front[2];
@@ -935,10 +937,12 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
                         S.u.t.rec[at][2] = c;
                         float4 P0, P1, P2;
                         fold_triangle(f.ox, f.oy, f.oz, dabs, a, b, c, P0, P1, P2);
-                        if (f.flags & INV_LAMBERT) P1.w = lambert_term(f, b, c); // once per record, not per shaded sample
-                        S.u.t.pre[at][0] = P0;
-                        S.u.t.pre[at][1] = P1;
-                        S.u.t.pre[at][2] = P2;
+                        // interleaved with the pair's other record: this one fills half (at & 1) of every float pair
+                        float* pp = (float*)&S.u.t.pre2[at >> 1][0] + (at & 1u);
+                        pp[0] = P0.x, pp[2] = P0.y, pp[4] = P0.z, pp[6] = P1.x, pp[8] = P1.y, pp[10] = P1.z;
+                        pp[12] = P2.x, pp[14] = P2.y, pp[16] = P2.z;
+                        pp[18] = pair_eps(f.ox, f.oy, f.oz, dabs, a, b, c);
+                        if (f.flags & INV_LAMBERT) S.lambert[at] = lambert_term(f, b, c); // once per record, not per shaded sample
                         S.quad[at] = quads;
                     } else {
                         S.overflow = 1;
@@ -967,6 +971,7 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
     if (stamps) t2 = __builtin_amdgcn_s_memtime();
     // ---- phase 3: this wave's quadrant ----
     const uint32_t nrec = S.n_rec;
+
     const uint32_t pix = py * f.w + px;
     // records whose box can touch this quadrant, as wave-uniform bit masks (64 records each)
     uint64_t rel[kBlockCap / 64];
@@ -988,16 +993,18 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
         Hit best = miss_hit();
 #pragma unroll
         for (int c = 0; c < kBlockCap / 64; c++) {
-            uint64_t todo = rel[c]; // wave-uniform
-            if (!todo) continue;
-            // cheap pass: which of the quadrant's records contain the sample (one bit per record, no divergence) ...
+            if (!rel[c]) continue;
+            // cheap pass: which of the quadrant's records contain the sample (one bit per record, no divergence), two
+            // records per step: the pairs with at least one record of this quadrant (wave-uniform) ...
+            uint64_t todo = (rel[c] | (rel[c] >> 1)) & 0x5555555555555555ull;
             uint64_t inside = 0;
             while (todo) {
-                const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t i = (uint32_t)__builtin_ctzll(todo); // even: the pair's first record
                 todo &= todo - 1ull;
-                const uint32_t j = (uint32_t)c * 64u + i;
-                if (mt_inside_folded(ray, S.u.t.pre[j][0], S.u.t.pre[j][1], S.u.t.pre[j][2])) inside |= 1ull << i;
+                const float4* q = S.u.t.pre2[((uint32_t)c * 64u + i) >> 1];
+                inside |= (uint64_t)mt_inside_pair(ray, q[0], q[1], q[2], q[3], q[4]) << i;
             }
+            inside &= rel[c]; // a pair's other record may belong to other quadrants only, or (last pair) not exist
             // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
             if (f.flags & kDebugSkipExact) inside = 0; // timing experiment only
             while (inside) {
@@ -1009,7 +1016,7 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
         float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
         if (best.key != kMissKey)
             shade_hit_with(f, best, S.u.t.rec[best.slot][0], S.u.t.rec[best.slot][1], S.u.t.rec[best.slot][2],
-                           S.u.t.pre[best.slot][1].w, r, g, b);
+                           (f.flags & INV_LAMBERT) ? S.lambert[best.slot] : 1.0f, r, g, b);
         sr = sr + r, sg = sg + g, sb = sb + b;
         if (s == 0) first = best;
     }
