@@ -84,33 +84,20 @@ __device__ __forceinline__ bool mt_inside(const Ray& r, const float4& A, const f
     return (det > 0.0f) & !(un < 0.0f) & !(un > det) & !(vn < 0.0f) & !(un + vn > det);
 }
 
-// The same decision from terms folded once per triangle, for rays that share the origin o (every primary ray
-// does): with t = o - v0,  det = e1 . (d x e2) = d . (e2 x e1),  un = t . (d x e2) = d . (e2 x t),  vn = d . (t x e1).
-// vn is computed exactly as mt_test computes it; det and un differ from mt_test's values by rounding only, so
-// the comparisons that involve them are widened by `eps` (many times that rounding): the result is true wherever
-// mt_inside is true and almost nowhere else.  P0 = (e2 x e1, eps), P1 = (e2 x t, 0), P2 = (t x e1, 0).
-__device__ __forceinline__ void fold_triangle(float ox, float oy, float oz, float dmax, const float4& A, const float4& B,
+// Terms of that decision folded once per triangle, for rays that share the origin o (every primary ray does):
+// with t = o - v0,  det = e1 . (d x e2) = d . (e2 x e1),  un = t . (d x e2) = d . (e2 x t),  vn = d . (t x e1):
+// P0 = e2 x e1, P1 = e2 x t, P2 = t x e1, so that each of the three is one dot product with the direction.
+__device__ __forceinline__ void fold_triangle(float ox, float oy, float oz, const float4& A, const float4& B,
                                               const float4& C, float4& P0, float4& P1, float4& P2) {
     const float tx = ox - A.x, ty = oy - A.y, tz = oz - A.z;
     P0.x = C.y * B.z - C.z * B.y, P0.y = C.z * B.x - C.x * B.z, P0.z = C.x * B.y - C.y * B.x;
     P1.x = C.y * tz - C.z * ty, P1.y = C.z * tx - C.x * tz, P1.z = C.x * ty - C.y * tx;
     P2.x = ty * B.z - tz * B.y, P2.y = tz * B.x - tx * B.z, P2.z = tx * B.y - ty * B.x; // mt_test's qvec
-    const float c1 = (fabsf(C.x) + fabsf(C.y)) + fabsf(C.z);
-    const float b1 = (fabsf(B.x) + fabsf(B.y)) + fabsf(B.z), t1 = (fabsf(tx) + fabsf(ty)) + fabsf(tz);
-    // every product in det and un is below dmax * c1 * max(b1, t1); a dozen roundings of 2^-24 each
-    P0.w = 0x1p-18f * (dmax * c1) * fmaxf(b1, t1);
-    P1.w = 0.0f, P2.w = 0.0f;
+    P0.w = 0.0f, P1.w = 0.0f, P2.w = 0.0f;
 }
 
-__device__ __forceinline__ bool mt_inside_folded(const Ray& r, const float4& P0, const float4& P1, const float4& P2) {
-    const float det = (r.dx * P0.x + r.dy * P0.y) + r.dz * P0.z;
-    const float un = (r.dx * P1.x + r.dy * P1.y) + r.dz * P1.z;
-    const float vn = (r.dx * P2.x + r.dy * P2.y) + r.dz * P2.z;
-    const float e = P0.w, hi = det + (e + e);
-    return (det > -e) & !(un < -e) & !(un > hi) & !(vn < 0.0f) & !(un + vn > hi);
-}
-
-// The same decision for two records at once in packed fp32 arithmetic.  The records' folded terms are stored
+// The decision for two records at once in packed fp32 arithmetic: true (per record) wherever mt_inside is true and
+// almost nowhere else.  The records' folded terms are stored
 // interleaved (record a in the low, record b in the high half of every pair of floats):
 //   q0 = (P0.x, P0.y)   q1 = (P0.z, P1.x)   q2 = (P1.y, P1.z)   q3 = (P2.x, P2.y)   q4 = (P2.z, eps)
 // Fused multiply-adds and another summation order than mt_test's: every value differs from mt_test's by rounding only,

@@ -336,7 +336,8 @@ struct TileLds {
             uint32_t frontier[2][kFrontierCap];
             uint2 ranges[kRangeCap];      // (first sorted triangle, count <= kRangeMax)
             float4 rec[CAP][3];          // candidate records A, B, C that survived the per-triangle test
-            float4 pre[CAP][3];          // their folded terms for the cheap inside test (fold_triangle)
+            float4 pre2[CAP / 2][5];     // folded terms of the cheap inside test, two records interleaved
+                                         // (mt_inside_pair)
         } t;
         uint32_t stack[kStack * 64]; // fallback: per-lane traversal by the first wave
     } u;
@@ -353,6 +354,7 @@ struct TileLds {
     uint32_t overflow;     // more subtrees or leaf ranges than the lists hold: per-lane traversal instead
     uint32_t rec_overflow; // more candidate records than the list holds: phase 3 runs in batches
     uint32_t rec_k[CAP]; // position of each record in the sorted triangle arrays
+    float lambert[CAP];  // Lambert factor of each record's triangle
 };
 
 // Append `flag` lanes' values to an LDS list: one counter update per wave, lanes ranked by ballot.
@@ -547,13 +549,15 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                     S.u.t.rec[at][1] = B;
                     S.u.t.rec[at][2] = C;
                     float4 P0, P1, P2;
-                    fold_triangle(f.ox, f.oy, f.oz, dabs, A, B, C, P0, P1, P2);
+                    fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
+                    // interleaved with the pair's other record: this one fills half (at & 1) of every float pair
+                    float* pp = (float*)&S.u.t.pre2[at >> 1][0] + (at & 1u);
+                    pp[0] = P0.x, pp[2] = P0.y, pp[4] = P0.z, pp[6] = P1.x, pp[8] = P1.y, pp[10] = P1.z;
+                    pp[12] = P2.x, pp[14] = P2.y, pp[16] = P2.z;
+                    pp[18] = pair_eps(f.ox, f.oy, f.oz, dabs, A, B, C);
                     // once per record instead of once per shaded sample (the batched variant shades from the
                     // triangle arrays and would not use it)
-                    if (!BATCHED && (f.flags & INV_LAMBERT)) P1.w = lambert_term(f, B, C);
-                    S.u.t.pre[at][0] = P0;
-                    S.u.t.pre[at][1] = P1;
-                    S.u.t.pre[at][2] = P2;
+                    if (!BATCHED && (f.flags & INV_LAMBERT)) S.lambert[at] = lambert_term(f, B, C);
                     if (BATCHED) S.rec_k[at] = k;
                 } else {
                     S.rec_overflow = 1;
@@ -605,8 +609,11 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
             for (uint32_t c = 0; c < nrec; c += 64) { // 64 records per mask
                 const uint32_t m = min(64u, nrec - c);
                 uint64_t inside = 0;
-                for (uint32_t i = 0; i < m; i++)
-                    inside |= (uint64_t)mt_inside_folded(ray, S.u.t.pre[c + i][0], S.u.t.pre[c + i][1], S.u.t.pre[c + i][2]) << i;
+                for (uint32_t i = 0; i < m; i += 2) { // two records per step
+                    const float4* q = S.u.t.pre2[(c + i) >> 1];
+                    inside |= (uint64_t)mt_inside_pair(ray, q[0], q[1], q[2], q[3], q[4]) << i;
+                }
+                if (m < 64u) inside &= (1ull << m) - 1ull; // the last pair may lack its second record
                 while (inside) {
                     const uint32_t j = c + (uint32_t)__ffsll((long long)inside) - 1u;
                     inside &= inside - 1ull;
@@ -616,7 +623,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
             float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
             if (best.key != kMissKey)
                 shade_hit_with(f, best, S.u.t.rec[best.slot][0], S.u.t.rec[best.slot][1], S.u.t.rec[best.slot][2],
-                               S.u.t.pre[best.slot][1].w, r, g, b);
+                               (f.flags & INV_LAMBERT) ? S.lambert[best.slot] : 1.0f, r, g, b);
             S.win[wave * 64u + lane] = make_float4(r, g, b, 0.0f);
             if (s == 0) first = best; // sample 0 is the first wave's
         }
@@ -644,17 +651,22 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                 __syncthreads();
             }
             const uint32_t nrec = min(S.n_rec, (uint32_t)kTileCap);
-            // cheap pass: which of this wave's records contain the sample (one bit per record, no divergence) ...
+            // cheap pass: which of this wave's records contain the sample (one bit per record, no divergence); the
+            // waves share the record pairs: pair p = wave + k * NW gives bits 2k and 2k + 1 ...
             uint64_t inside = 0;
-            for (uint32_t j = wave, i = 0; j < nrec; j += NW, i++)
-                inside |= (uint64_t)mt_inside_folded(ray, S.u.t.pre[j][0], S.u.t.pre[j][1], S.u.t.pre[j][2]) << i;
+            const uint32_t npairs = (nrec + 1u) >> 1;
+            for (uint32_t p = wave, k = 0; p < npairs; p += NW, k++) {
+                const float4* q = S.u.t.pre2[p];
+                inside |= (uint64_t)mt_inside_pair(ray, q[0], q[1], q[2], q[3], q[4]) << (2u * k);
+            }
             // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
             if (f.flags & kDebugSkipExact) inside = 0; // timing experiment only
             while (inside) {
                 const uint32_t i = (uint32_t)__ffsll((long long)inside) - 1u;
                 inside &= inside - 1ull;
-                const uint32_t j = wave + i * NW;
-                mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], batched ? S.rec_k[j] : j, best);
+                const uint32_t j = 2u * (wave + (i >> 1) * NW) + (i & 1u);
+                if (j < nrec) // the last pair may lack its second record
+                    mt_test(f, ray, S.u.t.rec[j][0], S.u.t.rec[j][1], S.u.t.rec[j][2], batched ? S.rec_k[j] : j, best);
             }
         }
         if (best.key != kMissKey) atomicMin(&S.best[lane], (unsigned long long)best.key);
@@ -674,7 +686,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                     shade_hit(f, h, TA[h.slot], TB[h.slot], TC[h.slot], r, g, b);
                 else
                     shade_hit_with(f, h, S.u.t.rec[h.slot][0], S.u.t.rec[h.slot][1], S.u.t.rec[h.slot][2],
-                                   S.u.t.pre[h.slot][1].w, r, g, b);
+                                   (f.flags & INV_LAMBERT) ? S.lambert[h.slot] : 1.0f, r, g, b);
                 if (s == 0) first = h;
             }
             sr = sr + r, sg = sg + g, sb = sb + b;
@@ -936,7 +948,7 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
                         S.u.t.rec[at][1] = b;
                         S.u.t.rec[at][2] = c;
                         float4 P0, P1, P2;
-                        fold_triangle(f.ox, f.oy, f.oz, dabs, a, b, c, P0, P1, P2);
+                        fold_triangle(f.ox, f.oy, f.oz, a, b, c, P0, P1, P2);
                         // interleaved with the pair's other record: this one fills half (at & 1) of every float pair
                         float* pp = (float*)&S.u.t.pre2[at >> 1][0] + (at & 1u);
                         pp[0] = P0.x, pp[2] = P0.y, pp[4] = P0.z, pp[6] = P1.x, pp[8] = P1.y, pp[10] = P1.z;
