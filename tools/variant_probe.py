@@ -46,18 +46,21 @@ def main():
     # several frames per launch (inv_render_batch), each into attachments of its own
     w, h = 1920, 1080
     cam, prm = R.camera_reference(w, h), R.make_params(w, h, flags=R.LAMBERT | R.INVERT | int(os.environ.get("PROBE_FLAGS", "0")))
-    for F in (2, 4, 8):
+    for F in [int(v) for v in os.environ.get("PROBE_FRAMES", "2,4,8").split(",")]:
         line = ["  %d frames per launch:" % F]
+        # PROBE_SETS = M: every slot rotates through M groups of F attachment sets (the footprint of the frames in
+        # flight against the 256 MB Infinity Cache: one 1080p set is 24.9 MB)
+        M = int(os.environ.get("PROBE_SETS", "1"))
         for S in (1, 2, 3):
-            planes = [torch.empty(3, w * h, dtype=torch.int32, device="cuda") for _ in range(S * F)]
+            planes = [torch.empty(3, w * h, dtype=torch.int32, device="cuda") for _ in range(S * F * M)]
             batches = [scene.make_batch([cam] * F, [prm] * F, [(p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr())
-                                                                 for p in planes[j * F:(j + 1) * F]]) for j in range(S)]
+                                                                 for p in planes[j * F:(j + 1) * F]]) for j in range(S * M)]
             K, best = 2400 // F, 1e9
             for rep in range(4):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(K):
-                    scene.render_batch(batches[i % S], i % S)
+                    scene.render_batch(batches[i % (S * M)], i % S)
                 torch.cuda.synchronize()
                 best = min(best, (time.perf_counter() - t0) / (K * F) * 1e6)
             line.append("x%d %6.2f us" % (S, best))
