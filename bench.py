@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--composite-frames", type=int, default=8, choices=range(1, 9),
                     help="N > 1, sparse composite: frames per submission and per gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-passes", action="store_true",
+                    help="skip the passes after the timed region (roofline.alone, roofline.streaming): under a "
+                         "profiler the kernel statistics then cover the timed region and its warm-up only")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
     ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
                     help="N > 1: gather only the tiles that can contain hits (sparse) or the whole frame (dense)")
@@ -341,7 +344,7 @@ def main():
         kernel_ms = ev_begin.elapsed_time(ev_end) / args.steps
 
     alone_ms = None
-    if slots_used:
+    if slots_used and not args.no_extra_passes:
         # after the timed region: the same submissions on one slot only, i.e. the launches with the GPU to themselves
         # (the last frame lands where the timed region left it)
         last_slot = submissions[-1][0]
@@ -357,7 +360,7 @@ def main():
     # the 256 MB Infinity Cache in front of HBM, part of the stores never has to reach HBM before it is overwritten.
     # The same job through four times as many sets (far more than that cache holds) shows the rate without that help.
     streaming = None
-    if slots_used and not turntable:
+    if slots_used and not turntable and not args.no_extra_passes:
         rotate = 4
         more = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif * fpl * (rotate - 1))]
         all_ptr = slot_ptr + [[p[i].data_ptr() for i in range(3)] for p in more]
