@@ -375,6 +375,28 @@ def test_batched_draws_match_the_oracle(oracle, bunny_path, bunny_mesh):
             prm = R.make_params(w, h, **kw)
             want = oracle.render_bvh(*bunny_mesh, oracle.camera_turntable(w, h, t), _oracle_params(oracle, prm))
             common.assert_frames_equal(got, want, "batch t=%.2f %dx%d" % (t, w, h))
+    # a frame with nothing on screen (scene behind the eye) and one without a depth attachment among ordinary ones
+    w, h = 640, 360
+    behind = R.camera_reference(w, h)
+    behind.view[14] = 5.0
+    cams = [R.camera_reference(w, h), behind, R.camera_turntable(w, h, 1.5)]
+    prm = R.make_params(w, h, flags=R.LAMBERT)
+    bufs = [torch.full((3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda") for _ in cams]
+    torch.cuda.synchronize()
+    scene.render_batch(scene.make_batch(cams, [prm] * 3, [(b[0].data_ptr(), 0 if i == 2 else b[1].data_ptr(), b[2].data_ptr())
+                                                          for i, b in enumerate(bufs)]), 0)
+    ctx.frame_wait(0)
+    ocams = [oracle.camera_reference(w, h), oracle.Camera.from_buffer_copy(bytes(behind)), oracle.camera_turntable(w, h, 1.5)]
+    for i, (b, ocam) in enumerate(zip(bufs, ocams)):
+        host = b.cpu().numpy()
+        want = oracle.render_bvh(*bunny_mesh, ocam, _oracle_params(oracle, prm))
+        assert np.array_equal(host[0].view(np.uint8).reshape(h, w, 4), want[0]), "colour, frame %d" % i
+        assert np.array_equal(host[2].view(np.uint32).reshape(h, w), want[2]), "primitive id, frame %d" % i
+        if i == 2:
+            assert (host[1] == 0x5A5A5A5A).all(), "a missing depth attachment must not be written"
+        else:
+            assert np.array_equal(host[1].view(np.uint32).reshape(h, w), want[1].view(np.uint32)), "depth, frame %d" % i
+    assert (bufs[1][2].cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all()
     # a bad frame anywhere in the batch refuses the whole batch before anything is drawn
     bufs = [torch.zeros(3, 64 * 64, dtype=torch.int32, device="cuda") for _ in range(2)]
     torch.cuda.synchronize()
