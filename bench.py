@@ -3,8 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-One step = one frame of the workload rendered through the C ABI (include/invert.h) with every input
-(triangles, LBVH) and output buffer resident in HBM.  On one GPU the frames are submitted --frames-per-launch at a time
+One step = one batch of --frames-per-step (default 64) frames of the workload rendered through the C ABI
+(include/invert.h) with every input (triangles, LBVH) and output buffer resident in HBM; a frame of the headline
+workload lasts a few microseconds, so a single frame per step would leave a handful of steps too short to time.  On one GPU the frames are submitted --frames-per-launch at a time
 (inv_render_batch, default 4: one launch of the tile kernel draws them all) and the submissions go round-robin to
 --frames-in-flight frame slots (default 2, the reference's MAX_FRAMES_IN_FLIGHT, src/invert.cpp:241), whose launches
 overlap on the GPU.  Every frame is a whole draw into attachments of its own (slots x frames-per-launch sets).
@@ -115,8 +116,11 @@ def cpu_baseline(wl, camera, budget_s=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=4000)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--frames-per-step", type=int, default=64,
+                    help="a step is one batch of this many frames of the workload (a single frame lasts a few "
+                         "microseconds: too little to time a handful of steps)")
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
                     help="one GPU: frame slots the submissions are dealt to")
@@ -155,6 +159,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    nframes, nwarm = args.steps * args.frames_per_step, args.warmup * args.frames_per_step  # frames timed / warmed up
     wl = WORKLOADS[args.workload]
     w, h, spp = wl["width"], wl["height"], wl["spp"]
     flags = wl["flags"] | (R.BRUTE_FORCE if args.brute_force else 0)
@@ -212,7 +217,7 @@ def main():
     # slots that is the duration of a launch that shares the GPU with the other slots' launches.  With several
     # GPUs the stream also carries the gather, so there a pair of events brackets every 4th render launch.
     every = 4
-    nev = (args.steps + every - 1) // every
+    nev = (nframes + every - 1) // every
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nev)]
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -223,6 +228,8 @@ def main():
 
         # Submission k draws frames k*fpl .. on slot k % fif into that slot's attachment sets; the argument arrays
         # are built once (the host work of a draw -- camera inverse, hit rectangle, grid -- stays in the call).
+        drawn = set()  # attachment sets (indices into the list passed as ptrs) some submission draws into
+
         def make_submissions(nframes, ptrs=None, rotate=1):
             # ptrs: attachment sets to draw into (default: the fif * fpl sets of the timed region); with rotate = M
             # every slot goes round M groups of fpl sets, so that M * fif * fpl sets are in use
@@ -234,11 +241,12 @@ def main():
                 group = j + fif * ((k // fif) % rotate)
                 subs.append((j, n, scene.make_batch([cams[(i + u) % len(cams)] if turntable else cam for u in range(n)],
                                                     [prm] * n, [ptrs[group * fpl + u] for u in range(n)])))
+                drawn.update(group * fpl + u for u in range(n))
                 i, k = i + n, k + 1
             return subs
 
-        submissions = make_submissions(args.steps)
-        warm_submissions = make_submissions(args.warmup)
+        submissions = make_submissions(nframes)
+        warm_submissions = make_submissions(nwarm)
 
     def run(subs):
         for j, n, batch in subs:
@@ -264,7 +272,7 @@ def main():
     if grouped:
         slot_streams = cb._slot_streams
         slot_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
-        groups, warm_groups = make_groups(args.steps), make_groups(args.warmup)
+        groups, warm_groups = make_groups(nframes), make_groups(nwarm)
 
     def step(i=None):
         timed = world > 1 and i is not None and i % every == 0
@@ -301,7 +309,7 @@ def main():
     elif slots_used:
         run(warm_submissions)
     else:
-        for _ in range(args.warmup):
+        for _ in range(nwarm):
             step()
     torch.cuda.synchronize()
     if world > 1:
@@ -324,7 +332,7 @@ def main():
             slot_ev[j][1].record(slot_streams[j])
         ctx.frames_join()  # the context's stream (and ev_end on it) waits for every slot
     else:
-        for i in range(args.steps):
+        for i in range(nframes):
             step(i)
     ev_end.record(stream)
     torch.cuda.synchronize()
@@ -341,7 +349,7 @@ def main():
         counts = [sum(1 for sub in submissions if sub[0] == j) for j in range(fif)]
         kernel_ms = sum(slot_ev[j][0].elapsed_time(slot_ev[j][1]) for j in range(fif) if counts[j]) / max(1, sum(counts))
     else:
-        kernel_ms = ev_begin.elapsed_time(ev_end) / args.steps
+        kernel_ms = ev_begin.elapsed_time(ev_end) / nframes
 
     alone_ms = None
     if slots_used and not args.no_extra_passes:
@@ -364,14 +372,14 @@ def main():
         rotate = 4
         more = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif * fpl * (rotate - 1))]
         all_ptr = slot_ptr + [[p[i].data_ptr() for i in range(3)] for p in more]
-        subs = make_submissions(args.steps, all_ptr, rotate)
-        run(make_submissions(min(args.steps, fif * fpl * rotate), all_ptr, rotate))  # touch every set once
+        subs = make_submissions(nframes, all_ptr, rotate)
+        run(make_submissions(min(nframes, fif * fpl * rotate), all_ptr, rotate))  # touch every set once
         torch.cuda.synchronize()
         ts = time.perf_counter()
         run(subs)
         torch.cuda.synchronize()
         streaming = (time.perf_counter() - ts, len(all_ptr))
-        if not all(torch.equal(slot_planes[0], p) for p in more[:min(len(more), max(0, args.steps - len(slot_planes)))]):
+        if not all(torch.equal(slot_planes[0], (slot_planes + more)[i]) for i in sorted(drawn)):
             raise SystemExit("the extra attachment sets hold different frames: timing rejected")
         del more
 
@@ -401,14 +409,13 @@ def main():
     if world == 1 and slots_used:
         j, n, _ = submissions[-1]
         planes = slot_planes[j * fpl + n - 1]  # the attachments of the last frame
-        used = min(len(slot_planes), args.steps + args.warmup)
-        if not turntable and not all(torch.equal(planes, p) for p in slot_planes[:used]):
+        if not turntable and not all(torch.equal(planes, slot_planes[i]) for i in sorted(drawn) if i < len(slot_planes)):
             raise SystemExit("the attachment sets hold different frames: timing rejected")
     if rank == 0:
         final = frame if world > 1 else planes
         hit_pixels = int((final[2] != -1).sum()) if world == 1 or rank == 0 else 0
-        rays_per_step = w * h * spp + ao_rays * hit_pixels  # primary + occlusion rays of the whole frame
-        value = rays_per_step * args.steps / elapsed / 1e6
+        rays_per_frame = w * h * spp + ao_rays * hit_pixels  # primary + occlusion rays of the whole frame
+        value = rays_per_frame * nframes / elapsed / 1e6
         # HBM roofline of the render kernel: every pixel's colour, depth and primitive id written once,
         # triangles (48 B) and LBVH nodes (64 B) read once per frame per GPU.
         alg_bytes = 12 * (npix if world > 1 else w * h) + scene_bytes  # per frame
@@ -422,8 +429,9 @@ def main():
             "config": {"workload": args.workload, "mesh": "bunny (2503 v / 4968 f, regenerated from the fixture)",
                        "width": w, "height": h, "spp": spp, "ao_rays": ao_rays, "hit_pixels": hit_pixels,
                        # 98.8 % of the primary rays miss the scene's bounds: the rate over rays of hit pixels only
-                       "hit_pixel_mrays_per_s": (hit_pixels * spp + ao_rays * hit_pixels) * args.steps / elapsed / 1e6,
-                       "rays_per_frame": rays_per_step, "flags": int(flags),
+                       "hit_pixel_mrays_per_s": (hit_pixels * spp + ao_rays * hit_pixels) * nframes / elapsed / 1e6,
+                       "rays_per_frame": rays_per_frame, "frames_per_step": args.frames_per_step,
+                       "us_per_frame": elapsed / nframes * 1e6, "flags": int(flags),
                        "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0%s" % (
                                            args.composite, world, ", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
@@ -434,8 +442,8 @@ def main():
                                     else "k_render_tile") + ("+k_ao" if ao_rays else ""),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": launch_bytes, "frames_per_launch": fpl,
                          # the same bytes over the frame time of the whole job (kernels of different slots overlap)
-                         "job": {"achieved": alg_bytes * args.steps / elapsed / 1e9,
-                                 "frac": alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}},
+                         "job": {"achieved": alg_bytes * nframes / elapsed / 1e9,
+                                 "frac": alg_bytes * nframes / elapsed / 1e9 / HBM_PEAK_GBS}},
             "cpu_baseline": None,
         }
         set_mb = 12 * (w * h) / 1e6
@@ -445,16 +453,16 @@ def main():
         if streaming is not None:  # the same job through 4x as many attachment sets (more than the Infinity Cache holds)
             st, nsets = streaming
             result["roofline"]["streaming"] = {"attachment_sets": nsets, "attachment_mb": set_mb * nsets,
-                                               "ms_per_step": st / args.steps * 1e3,
-                                               "value": rays_per_step * args.steps / st / 1e6,
-                                               "achieved": alg_bytes * args.steps / st / 1e9,
-                                               "frac": alg_bytes * args.steps / st / 1e9 / HBM_PEAK_GBS}
+                                               "ms_per_step": st / args.steps * 1e3, "us_per_frame": st / nframes * 1e6,
+                                               "value": rays_per_frame * nframes / st / 1e6,
+                                               "achieved": alg_bytes * nframes / st / 1e9,
+                                               "frac": alg_bytes * nframes / st / 1e9 / HBM_PEAK_GBS}
         if alone_ms is not None:  # the same kernel when no other slot's kernel shares the GPU with it
             result["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": launch_bytes / (alone_ms * 1e-3) / 1e9,
                                            "frac": launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
-            base, oracle_out, work = cpu_baseline(wl, cams[(args.steps - 1) % len(cams)] if turntable else cam)
+            base, oracle_out, work = cpu_baseline(wl, cams[(nframes - 1) % len(cams)] if turntable else cam)
             # outputs are compared before the timing is accepted
             got = planes.cpu().numpy()
             ok = (np.array_equal(got[2].view(np.uint32).reshape(h, w), oracle_out[2])

@@ -8,7 +8,7 @@ R=$(pwd)
 O=$R/gpurun_out/$TAG
 rm -rf "$O" && mkdir -p "$O"
 export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 4000 --warmup 400"
+B="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 60 --warmup 6"
 timeout -k 10 200 python3 bench.py > "$O/bench_default.json"
 timeout -k 10 200 python3 bench.py --workload bunny_4k_16spp > "$O/bench_4k_16spp.json"
 timeout -k 10 200 python3 bench.py --workload bunny_1080p_ao64 > "$O/bench_ao64.json"
