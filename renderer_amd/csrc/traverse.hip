@@ -387,16 +387,19 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
 
     // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
     //      is still a subtree after that is opened breadth-first ----
+    // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
+    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
+    float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
+    if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
     if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.rec_overflow = 0, S.n_groups = 0;
     const float srgb_entry = kSrgbT[tid & 255u]; // stored to LDS later: the load stays in flight behind the first steps
     if (tid < 64) S.best[tid] = kMissKey;
     __syncthreads();
-    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
         const uint32_t g = base + tid;
         bool in = false;
         if (g < ngroups) {
-            const float4 lo = cut_groups[2 * (size_t)g], hi = cut_groups[2 * (size_t)g + 1];
+            const float4 lo = base ? cut_groups[2 * (size_t)g] : g_lo, hi = base ? cut_groups[2 * (size_t)g + 1] : g_hi;
             in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
         }
         const uint32_t at = wave_append(&S.n_groups, in, lane);
@@ -761,16 +764,19 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
 
     // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
     //      is still a subtree after that is opened breadth-first ----
+    // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
+    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
+    float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
+    if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
     if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
     const float srgb_entry = kSrgbT[tid]; // stored to LDS later: the load stays in flight behind the first steps
     __syncthreads();
     if (stamps) ta = __builtin_amdgcn_s_memtime();
-    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
         const uint32_t g = base + tid;
         bool in = false;
         if (g < ngroups) {
-            const float4 lo = cut_groups[2 * (size_t)g], hi = cut_groups[2 * (size_t)g + 1];
+            const float4 lo = base ? cut_groups[2 * (size_t)g] : g_lo, hi = base ? cut_groups[2 * (size_t)g + 1] : g_hi;
             in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
         }
         const uint32_t at = wave_append(&S.n_groups, in, lane);
