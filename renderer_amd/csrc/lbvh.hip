@@ -360,41 +360,46 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
 //    last sorted leaf under the node (written by the hierarchy kernel).  union_box[i] (8 floats)
 //    carries the node's own box and height upwards.
 // ------------------------------------------------------------------------------------------
-// Call with the whole wave converged (`live` selects the lanes that have a node).  The ready list's counter is
-// one address for the whole grid, so a wave updates it once for all of its lanes.
-__device__ __forceinline__ void arrive_at(bool live, uint32_t node, uint32_t* __restrict__ arrive,
-                                          uint32_t* __restrict__ next, uint32_t* __restrict__ next_count) {
-    const bool second = live && node != 0xFFFFFFFFu && atomicAdd(&arrive[node], 1u) == 1u; // ready next launch
-    const uint64_t mask = __ballot(second);
-    if (!mask) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (second) next[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = node;
+// Appends the flagged lanes' values to a list in global memory.  The list's counter is one address for the whole
+// grid (a few hundred thousand updates of one address take longer than the rest of the refit), so a workgroup of NT
+// threads updates it once for all of its lanes: ballots rank the lanes within a wave, LDS ranks the waves.
+// Call from every thread of the workgroup (three barriers).
+template <int NT>
+__device__ __forceinline__ void block_append(bool flag, uint32_t value, uint32_t* __restrict__ list,
+                                             uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_wave[NT / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t mask = __ballot(flag);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < NT / 64; w++) total += s_wave[w];
+        s_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    if (flag) {
+        uint32_t at = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; w++) at += s_wave[w];
+        list[at] = value;
+    }
+    __syncthreads(); // the next call overwrites s_wave
 }
 
 // The leaves' arrivals need no atomics: how many of a node's children are leaves is in its child references.
 // Sets every arrival counter to that number and lists the nodes over two leaves as the first level.
-__global__ __launch_bounds__(256) void k_refit_leaves(uint32_t ninternal, const uint32_t* __restrict__ child,
-                                                      uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
-                                                      uint32_t* __restrict__ next_count) {
+__global__ __launch_bounds__(1024) void k_refit_leaves(uint32_t ninternal, const uint32_t* __restrict__ child,
+                                                       uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
+                                                       uint32_t* __restrict__ next_count) {
     const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t leaves = 0;
     if (node < ninternal) {
-        leaves = (child[2 * (size_t)node] >> 31) + (child[2 * (size_t)node + 1] >> 31);
+        const uint2 c = ((const uint2*)child)[node];
+        leaves = (c.x >> 31) + (c.y >> 31);
         arrive[node] = leaves;
     }
-    const bool ready = leaves == 2u;
-    const uint64_t mask = __ballot(ready);
-    if (!mask) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (ready) next[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = node;
+    block_append<1024>(leaves == 2u, node, next, next_count);
 }
 
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
@@ -444,11 +449,13 @@ __global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ 
                                                      uint32_t* __restrict__ next_count) {
     // The level's size is read on the device, so the host can queue several levels without waiting for each.
     const uint32_t nready = *ready_count;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < nready; base += gridDim.x * blockDim.x) { // wave-uniform
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nready; base += gridDim.x * blockDim.x) { // block-uniform
         const uint32_t q = base + threadIdx.x;
         uint32_t up = 0xFFFFFFFFu;
         if (q < nready) up = refit_node(TA, TB, TC, child, parent, ready[q], union_box, nodes);
-        arrive_at(q < nready, up, arrive, next, next_count);
+        // the second child to arrive makes the parent ready for the next launch
+        const bool second = up != 0xFFFFFFFFu && atomicAdd(&arrive[up], 1u) == 1u;
+        block_append<256>(second, up, next, next_count);
     }
 }
 
@@ -652,7 +659,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        sc.nodes);
     HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 1) * 4, s));
-    hipLaunchKernelGGL(k_refit_leaves, dim3((n - 1 + 255) / 256), blk, 0, s, n - 1, sc.child, arrive, ready[0],
+    hipLaunchKernelGGL(k_refit_leaves, dim3((n - 1 + 1023) / 1024), dim3(1024), 0, s, n - 1, sc.child, arrive, ready[0],
                        ready_count);
     HIP_RET(hipGetLastError());
     // One launch per tree level; level L reads its size from ready_count[L] on the device and appends the nodes that
