@@ -145,6 +145,63 @@ def test_sparse_tiles_gather_to_rank0(tmp_path, world, w, h, tile):
     assert open(result).read() == "ok"
 
 
+def _grouped_worker(rank, world, port, w, h, tile, rect, frames, used, result_path):
+    """The grouped sparse composite's exchange (renderer_amd.dist.SparseCompositeBatch.gather): `frames` frames per
+    buffer set, of which a short last group uses only the first `used`; one gather of the leading slices, and on rank 0
+    plane k of frame j of rank r sits r * frames * 3 * n + (3 * j + k) * n elements into the receive buffer, which is
+    what inv_deinterleave_sparse is given (rank_stride = frames * 3 * n, plane_stride = n, nplanes = 3 * used)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    color, depth, primid = common.golden_frame("bunny_512")
+    full = [np.ascontiguousarray(color).view(np.uint32).reshape(512, 512)[:h, :w],
+            depth.view(np.uint32)[:h, :w], primid[:h, :w]]
+    prm = R.make_params(w, h, tile=tile, rank=rank, nranks=world, flags=R.SPARSE)
+    grid, npix, ids = R.sparse_layout(prm, rect)
+    _, n, _ = R.sparse_layout(R.make_params(w, h, tile=tile, rank=1, nranks=world, flags=R.SPARSE), rect)
+    tiles_x = (w + tile - 1) // tile
+    planes = torch.zeros(frames, 3, n, dtype=torch.int32)
+    if rank > 0:  # frame j of this rank: its tiles cut out of the full frame, every value XOR j
+        for j in range(frames):
+            for k in range(3):
+                slots = np.zeros((n // (tile * tile), tile, tile), np.uint32)
+                for slot, tid in enumerate(ids):
+                    ty, tx = divmod(int(tid), tiles_x)
+                    part = full[k][ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] ^ np.uint32(j)
+                    slots[slot, :part.shape[0], :part.shape[1]] = part
+                planes[j, k] = torch.from_numpy(slots.reshape(-1).view(np.int32))
+    if rank == 0:
+        gathered = torch.full((world, frames, 3, n), 0x3C3C3C3C, dtype=torch.int32)
+        dist.gather(planes[:used], [gathered[r, :used] for r in range(world)], dst=0)
+        flat = gathered.numpy().view(np.uint32).reshape(-1)
+        ok = True
+        for j in range(used):
+            for k in range(3):
+                for t in range(grid[2] * grid[3]):
+                    r, slot = t % world, t // world
+                    if r == 0:
+                        continue
+                    ty, tx = grid[1] + t // grid[2], grid[0] + t % grid[2]
+                    y1, x1 = min((ty + 1) * tile, h), min((tx + 1) * tile, w)
+                    at = r * frames * 3 * n + (3 * j + k) * n + slot * tile * tile
+                    got = flat[at:at + tile * tile].reshape(tile, tile)[:y1 - ty * tile, :x1 - tx * tile]
+                    ok = ok and np.array_equal(got, full[k][ty * tile:y1, tx * tile:x1] ^ np.uint32(j))
+        ok = ok and bool((gathered[1:, used:] == 0x3C3C3C3C).all())  # frames past the short group are not touched
+        with open(result_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    else:
+        dist.gather(planes[:used], None, dst=0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,tile,frames,used", [(2, 512, 512, 64, 4, 4), (3, 500, 300, 32, 8, 3)])
+def test_grouped_sparse_gather(tmp_path, world, w, h, tile, frames, used):
+    result = str(tmp_path / "result.txt")
+    mp.spawn(_grouped_worker, args=(world, _free_port(), w, h, tile, BUNNY_RECT_512, frames, used, result), nprocs=world,
+             join=True)
+    assert open(result).read() == "ok"
+
+
 def test_sparse_layout_deals_each_grid_tile_once():
     w, h, tile = 1920, 1080, 64
     rect = (880, 301, 1086, 497)  # the bunny's footprint at 1080p
