@@ -516,17 +516,30 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
         for (int c = 0; c < 4; c++) dabs = fmaxf(dabs, fmaxf(fmaxf(fabsf(cdx[c]), fabsf(cdy[c])), fabsf(cdz[c])));
         dabs = dabs + dabs;
         const uint32_t nslots = (r1 - r0) * kRangeMax;
-        for (uint32_t base = 0; base < nslots; base += NT) { // block-uniform trip count
-            const uint32_t q = base + tid;
-            bool keep = false;
-            uint32_t k = 0;
-            float4 A, B, C;
-            if (q < nslots) {
-                const uint2 rg = S.u.t.ranges[r0 + q / kRangeMax];
-                const uint32_t off = q % kRangeMax;
-                if (off < rg.y) {
-                    k = rg.x + off;
-                    A = TA[k], B = TB[k], C = TC[k];
+        for (uint32_t base = 0; base < nslots; base += 2u * NT) { // block-uniform trip count; two triangles per lane
+            float4 A2[2], B2[2], C2[2];                           // and trip, all loads in flight before the first test
+            uint32_t k2[2] = {0, 0};
+            bool have[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t q = base + (uint32_t)u * NT + tid;
+                have[u] = false;
+                if (q < nslots) {
+                    const uint2 rg = S.u.t.ranges[r0 + q / kRangeMax];
+                    const uint32_t off = q % kRangeMax;
+                    if (off < rg.y) {
+                        k2[u] = rg.x + off;
+                        have[u] = true, A2[u] = TA[k2[u]], B2[u] = TB[k2[u]], C2[u] = TC[k2[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (base + (uint32_t)u * NT >= nslots) break; // block-uniform
+                bool keep = false;
+                const uint32_t k = k2[u];
+                const float4 A = A2[u], B = B2[u], C = C2[u];
+                if (have[u]) {
                     const float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
                     const float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
                     keep = box_in_frustum(fr, fminf(A.x, fminf(bx, cx)), fminf(A.y, fminf(by, cy)),
@@ -544,26 +557,26 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                     }
                     keep = keep && !(dmax < -1e-4f * scale);
                 }
-            }
-            const uint32_t at = wave_append(&S.n_rec, keep, lane);
-            if (keep) {
-                if (at < (uint32_t)kTileCap) {
-                    S.u.t.rec[at][0] = A;
-                    S.u.t.rec[at][1] = B;
-                    S.u.t.rec[at][2] = C;
-                    float4 P0, P1, P2;
-                    fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
-                    // interleaved with the pair's other record: this one fills half (at & 1) of every float pair
-                    float* pp = (float*)&S.u.t.pre2[at >> 1][0] + (at & 1u);
-                    pp[0] = P0.x, pp[2] = P0.y, pp[4] = P0.z, pp[6] = P1.x, pp[8] = P1.y, pp[10] = P1.z;
-                    pp[12] = P2.x, pp[14] = P2.y, pp[16] = P2.z;
-                    pp[18] = pair_eps(f.ox, f.oy, f.oz, dabs, A, B, C);
-                    // once per record instead of once per shaded sample (the batched variant shades from the
-                    // triangle arrays and would not use it)
-                    if (!BATCHED && (f.flags & INV_LAMBERT)) S.lambert[at] = lambert_term(f, B, C);
-                    if (BATCHED) S.rec_k[at] = k;
-                } else {
-                    S.rec_overflow = 1;
+                const uint32_t at = wave_append(&S.n_rec, keep, lane);
+                if (keep) {
+                    if (at < (uint32_t)kTileCap) {
+                        S.u.t.rec[at][0] = A;
+                        S.u.t.rec[at][1] = B;
+                        S.u.t.rec[at][2] = C;
+                        float4 P0, P1, P2;
+                        fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
+                        // interleaved with the pair's other record: this one fills half (at & 1) of every float pair
+                        float* pp = (float*)&S.u.t.pre2[at >> 1][0] + (at & 1u);
+                        pp[0] = P0.x, pp[2] = P0.y, pp[4] = P0.z, pp[6] = P1.x, pp[8] = P1.y, pp[10] = P1.z;
+                        pp[12] = P2.x, pp[14] = P2.y, pp[16] = P2.z;
+                        pp[18] = pair_eps(f.ox, f.oy, f.oz, dabs, A, B, C);
+                        // once per record instead of once per shaded sample (the batched variant shades from the
+                        // triangle arrays and would not use it)
+                        if (!BATCHED && (f.flags & INV_LAMBERT)) S.lambert[at] = lambert_term(f, B, C);
+                        if (BATCHED) S.rec_k[at] = k;
+                    } else {
+                        S.rec_overflow = 1;
+                    }
                 }
             }
         }
