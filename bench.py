@@ -270,7 +270,7 @@ def main():
                 cb.scatter_received(k, n)
 
     if grouped:
-        slot_streams = cb._slot_streams
+        slot_streams = cb.slot_streams
         slot_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
         groups, warm_groups = make_groups(nframes), make_groups(nwarm)
 

@@ -377,6 +377,8 @@ class Scene:
         key = (slot, color_ptr, depth_ptr, primid_ptr)
         out = cache.get(key)
         if out is None:
+            if len(cache) >= 64:  # callers cycle through a few attachment sets; anything else just rebuilds the struct
+                cache.clear()
             out = cache[key] = Outputs(color_ptr or None, depth_ptr or None, primid_ptr or None, 1)
         rc = lib().inv_render_in_flight(self._h, slot, C.byref(cam), C.byref(prm), C.byref(out))
         if rc:

@@ -519,14 +519,14 @@ namespace {
 // Argument checks of a draw and the per-frame constants the kernels take.
 int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_params* params, FrameK* fk) {
     if (params->ao_rays != 0 && params->spp > 1)
-        return fail(INV_ERR_UNSUPPORTED, "inv_render: ambient occlusion is defined for one sample per pixel");
-    if (params->ao_rays > 4096) return fail(INV_ERR_ARG, "inv_render: at most 4096 ambient-occlusion rays per pixel");
+        return fail(INV_ERR_UNSUPPORTED, "draw: ambient occlusion is defined for one sample per pixel");
+    if (params->ao_rays > 4096) return fail(INV_ERR_ARG, "draw: at most 4096 ambient-occlusion rays per pixel");
     {
         // Bits above the INV_* flags switch parts of the kernels off for timing experiments (tools/phase_timing.py,
         // tools/tile_stats.py) and make the images wrong: they are refused unless INV_TIMING_SWITCHES is set.
         constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE | INV_BLOCKS;
         static const bool allow = std::getenv("INV_TIMING_SWITCHES") != nullptr;
-        if ((params->flags & ~known) && !allow) return fail(INV_ERR_ARG, "inv_render: unknown bits in params.flags");
+        if ((params->flags & ~known) && !allow) return fail(INV_ERR_ARG, "draw: unknown bits in params.flags");
     }
     FrameK& f = *fk;
     std::memset(&f, 0, sizeof f);

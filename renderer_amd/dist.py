@@ -154,7 +154,7 @@ class SparseCompositeBatch:
             ptrs = [tuple(outs[j, p].data_ptr() for p in range(3)) for j in range(F)]
             # batches of 1 .. F frames (the last group of a run may be short)
             self._batches.append([scene.make_batch([cam] * m, [self.prm] * m, ptrs[:m]) for m in range(1, F + 1)])
-        self._slot_streams = [torch.cuda.ExternalStream(scene.ctx.frame_stream(k)) for k in range(sets)]
+        self.slot_streams = [torch.cuda.ExternalStream(scene.ctx.frame_stream(k)) for k in range(sets)]
         self._done = [torch.cuda.Event() for _ in range(sets)]
         torch.cuda.synchronize()  # the fills above ran on torch's stream, which the slots do not wait for
 
@@ -183,7 +183,7 @@ class SparseCompositeBatch:
             self.scene.ctx.deinterleave_sparse(self.prm0, self.rect, self.gathered[k].data_ptr(), F * 3 * s, s, 3 * n,
                                                self.frames[k].data_ptr(), self.width * self.height)
         self._done[k].record()
-        self._slot_streams[k].wait_event(self._done[k])
+        self.slot_streams[k].wait_event(self._done[k])
 
     def composite(self, k: int, n: int | None = None):
         self.gather(k, n)
