@@ -462,6 +462,51 @@ def test_pinned_mesh_builds_the_same_scene(gpu_ctx, bunny_path):
     empty.close()
 
 
+def test_headless_host_program(oracle, bunny_path, bunny_mesh, tmp_path):
+    """tools/headless/invert_headless (C++ on the C ABI: load, build, frame loop with frames in flight, attachments
+    written out): the files of the last frame against the golden (parity mode) and the oracle (turntable)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "headless", "invert_headless")
+    if not os.path.exists(exe):
+        pytest.fail("tools/headless/invert_headless is not built (python -c 'import __graft_entry__ as g; g.build()')")
+
+    def run(*args):
+        p = subprocess.run([exe, "--obj", bunny_path, *args], capture_output=True, text=True, timeout=100)
+        assert p.returncode == 0, p.stdout + p.stderr
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    def read(prefix, w, h):
+        raw = open(prefix + ".ppm", "rb").read()
+        head = ("P6\n%d %d\n255\n" % (w, h)).encode()
+        rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)
+        raw = open(prefix + ".pfm", "rb").read()
+        head = ("Pf\n%d %d\n-1.0\n" % (w, h)).encode()
+        depth = np.frombuffer(raw[len(head):], "<f4").reshape(h, w)[::-1]
+        primid = np.frombuffer(open(prefix + ".pid", "rb").read()[16:], "<u4").reshape(h, w)
+        return rgb, depth, primid
+
+    out = str(tmp_path / "parity")
+    r = run("--width", "512", "--height", "512", "--frames", "5", "--in-flight", "2", "--per-launch", "2", "--out", out)
+    assert r["triangles"] == 4968 and r["frames"] == 5 and r["hit_pixels_last_frame"] == 5651
+    rgb, depth, primid = read(out, 512, 512)
+    color, gdepth, gprimid = common.golden_frame("bunny_512")
+    assert np.array_equal(rgb, color[..., [2, 1, 0]]) and np.array_equal(primid, gprimid)
+    assert np.array_equal(depth.view(np.uint32), gdepth.view(np.uint32))
+
+    out = str(tmp_path / "turn")
+    w, h, frames = 640, 360, 7
+    r = run("--width", str(w), "--height", str(h), "--frames", str(frames), "--in-flight", "3", "--per-launch", "1",
+            "--turntable", "--lambert", "--invert", "--pin", "--out", out)
+    assert r["flags"] == (R.LAMBERT | R.INVERT) and r["us_per_frame"] > 0
+    rgb, depth, primid = read(out, w, h)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_turntable(w, h, (frames - 1) / 60.0),
+                             oracle.make_params(w, h, flags=R.LAMBERT | R.INVERT))
+    assert np.array_equal(rgb, want[0][..., [2, 1, 0]]) and np.array_equal(primid, want[2])
+    assert np.array_equal(depth.view(np.uint32), want[1].view(np.uint32))
+
+
 def test_errors(bunny_scene):
     cam = R.camera_reference(64, 64)
     with pytest.raises(R.InvertError):
