@@ -507,6 +507,29 @@ def test_headless_host_program(oracle, bunny_path, bunny_mesh, tmp_path):
     assert np.array_equal(depth.view(np.uint32), want[1].view(np.uint32))
 
 
+def test_8k_frame_properties(bunny_scene, gpu_ctx):
+    """7680x4320 (33 M pixels, far beyond what the oracle renders in seconds): the 8x8-tile variant, the 16x16-block
+    variant and the per-lane traversal must agree bit for bit, the background must hold the clear values, and the
+    covered area must be 16 times the 1080p one to within the silhouette's edge pixels."""
+    import torch
+    w, h = 7680, 4320
+    cam = R.camera_reference(w, h)
+    bufs = {}
+    for name, flags in (("tiles", 0), ("blocks", R.BLOCKS), ("lanes", R.LANE_TRAVERSAL)):
+        b = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
+        bunny_scene.render_device(cam, R.make_params(w, h, flags=flags | R.LAMBERT), b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
+        bufs[name] = b
+    gpu_ctx.synchronize()
+    assert torch.equal(bufs["tiles"], bufs["blocks"]) and torch.equal(bufs["tiles"], bufs["lanes"])
+    t = bufs["tiles"]
+    miss = t[2] == -1
+    hits = int((~miss).sum())
+    assert abs(hits - 16 * 25139) < 0.01 * 16 * 25139
+    assert bool((t[1][miss] == 0x3F800000).all()) and bool((t[0][miss] == -16777216).all())  # depth 1.0, colour (0,0,0,255)
+    depth = t[1][~miss].view(torch.float32)
+    assert float(depth.min()) > 0.90 and float(depth.max()) < 0.92  # the bunny's depth range (0.9028 .. 0.9150)
+
+
 def test_errors(bunny_scene):
     cam = R.camera_reference(64, 64)
     with pytest.raises(R.InvertError):

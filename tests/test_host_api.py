@@ -147,11 +147,20 @@ def test_tile_layout():
         assert (ids % 8 == r).all()
         total += list(ids)
     assert sorted(total) == list(range(510))
-    for bad in (dict(tile=12), dict(rank=3, nranks=2), dict(width=0)):
+    for bad in (dict(tile=12), dict(rank=3, nranks=2), dict(width=0), dict(tile=2048)):
         kw = dict(width=64, height=64)
         kw.update(bad)
         with pytest.raises(R.InvertError):
             R.tile_layout(R.make_params(**kw))
+    # the largest frames: up to 2^31 - 1 pixels are laid out (64-bit pixel counts), more is refused
+    npix, ids = R.tile_layout(R.make_params(46340, 46340))
+    assert npix == 46340 * 46340 and len(ids) == 725 * 725
+    npix, _ = R.tile_layout(R.make_params(65535, 32767, tile=1024, rank=5, nranks=7))
+    assert npix == -(-(64 * 32) // 7) * 1024 * 1024
+    for w, h in ((46341, 46341), (65536, 32768), (0xFFFFFFFF, 0xFFFFFFFF)):
+        with pytest.raises(R.InvertError) as e:
+            R.tile_layout(R.make_params(w, h))
+        assert e.value.code == api.ERR_ARG
 
 
 def test_no_gpu_is_a_loud_error():
