@@ -178,7 +178,8 @@ int inv_frame_stream(inv_ctx* ctx, uint32_t slot, void** hip_stream);
  * attachments of different frames must not overlap).  Frames the tile kernel can draw directly into device
  * attachments (LBVH traversal, no occlusion rays; shards of several ranks included) share launches, up to eight frames each, so that the
  * dispatch gap and the wait for a frame's slowest tiles are paid once per launch instead of once per frame;
- * anything else is drawn frame after frame.  `slot` is a frame slot (see inv_render_in_flight) or INV_CONTEXT_STREAM
+ * a frame that cannot share (occlusion rays, host attachments, four or more samples per pixel, triangles far smaller
+ * than a pixel, another traversal) is drawn on its own between the shared launches.  `slot` is a frame slot (see inv_render_in_flight) or INV_CONTEXT_STREAM
  * for the context's own stream. */
 #define INV_CONTEXT_STREAM 0xFFFFFFFFu
 int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const inv_camera* cams, const inv_params* params,

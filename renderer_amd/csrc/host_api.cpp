@@ -645,35 +645,33 @@ int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const in
     // every frame is checked before anything is enqueued
     FrameK fk[INV_BATCH_MAX];
     Outputs dev[INV_BATCH_MAX];
-    bool one_launch = true;
-    const bool kept = nframes <= INV_BATCH_MAX; // the first pass's constants serve the launch
     for (uint32_t i = 0; i < nframes; i++) {
-        FrameK& f = fk[i % INV_BATCH_MAX];
+        int rc = prepare_frame(scene, &cams[i], &params[i], &fk[0]);
+        if (rc != INV_OK) return rc;
+    }
+    // Frames that can share a launch are collected (up to INV_BATCH_MAX); a frame that cannot (occlusion rays, host
+    // attachments, another traversal, a variant of the tile kernel other than the blocks) is drawn on its own after
+    // the launch of those collected before it.  Everything runs on one stream, and the attachments do not overlap.
+    uint32_t pending = 0;
+    const auto flush = [&]() -> int {
+        if (pending) HIP_TRY(launch_render_batch(stream, fk, dev, pending, scene->d));
+        pending = 0;
+        return INV_OK;
+    };
+    for (uint32_t i = 0; i < nframes; i++) {
+        FrameK& f = fk[pending];
         int rc = prepare_frame(scene, &cams[i], &params[i], &f);
         if (rc != INV_OK) return rc;
         const Outputs o = {(uint8_t*)outs[i].color, (float*)outs[i].depth, (uint32_t*)outs[i].primid};
-        one_launch = one_launch && outs[i].on_device && params[i].ao_rays == 0 &&
-                     tile_batchable(f, scene->d, o);
-    }
-    if (!one_launch) { // the same draws one after the other (occlusion rays, host attachments, other traversals ...)
-        for (uint32_t i = 0; i < nframes; i++) {
-            int rc = render_on(scene, stream, *fs, &cams[i], &params[i], &outs[i]);
-            if (rc != INV_OK) return rc;
+        if (outs[i].on_device && params[i].ao_rays == 0 && tile_batchable(f, scene->d, o)) {
+            dev[pending++] = o;
+            if (pending == INV_BATCH_MAX && (rc = flush()) != INV_OK) return rc;
+        } else {
+            if ((rc = flush()) != INV_OK) return rc;
+            if ((rc = render_on(scene, stream, *fs, &cams[i], &params[i], &outs[i])) != INV_OK) return rc;
         }
-        return INV_OK;
     }
-    for (uint32_t i0 = 0; i0 < nframes; i0 += INV_BATCH_MAX) {
-        const uint32_t n = std::min<uint32_t>(INV_BATCH_MAX, nframes - i0);
-        for (uint32_t i = 0; i < n; i++) {
-            if (!kept) {
-                int rc = prepare_frame(scene, &cams[i0 + i], &params[i0 + i], &fk[i]);
-                if (rc != INV_OK) return rc;
-            }
-            dev[i] = {(uint8_t*)outs[i0 + i].color, (float*)outs[i0 + i].depth, (uint32_t*)outs[i0 + i].primid};
-        }
-        HIP_TRY(launch_render_batch(stream, fk, dev, n, scene->d));
-    }
-    return INV_OK;
+    return flush();
 }
 
 int inv_frame_wait(inv_ctx* ctx, uint32_t slot) {

@@ -341,22 +341,25 @@ def test_frames_in_flight_match_the_oracle(oracle, bunny_path, bunny_mesh):
 
 
 def test_batched_draws_match_the_oracle(oracle, bunny_path, bunny_mesh):
-    """inv_render_batch: frames of different cameras, extents and flags in one submission.  The first batch shares
-    launches of the tile kernel (eleven frames: one launch of eight and one of three), the second contains frames that
-    cannot (occlusion rays, per-lane traversal) and is drawn frame after frame; both on a frame slot and on the
-    context's stream."""
+    """inv_render_batch: frames of different cameras, extents and flags in one submission, on frame slots and on the
+    context's stream; frames that can share launches of the tile kernel do, the others are drawn in between."""
     import torch
     torch.cuda.set_device(0)
     ctx = R.Context(0)
     scene = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
+    # Ten frames that can share launches (at least 720p: few triangles per tile; fewer than four samples per pixel; no
+    # occlusion rays): one launch of eight and one of two, with frames in between that are drawn on their own (tiny
+    # extents, where triangles are smaller than pixels; five samples per pixel).
     shared = [(0.1 * i, w, h, kw) for i, (w, h, kw) in enumerate([
-        (1920, 1080, dict(flags=R.LAMBERT | R.INVERT)), (640, 360, dict(flags=R.LAMBERT, spp=4, seed=3)),
-        (1280, 720, dict(flags=0)), (333, 250, dict(flags=R.INVERT | R.RGBA)), (64, 64, dict(flags=R.LAMBERT)),
-        (1920, 1080, dict(flags=0)), (800, 600, dict(flags=R.LAMBERT, spp=2, seed=9)), (1001, 3, dict(flags=0)),
-        (512, 512, dict(flags=R.INVERT)), (1024, 768, dict(flags=R.LAMBERT | R.INVERT, spp=5)), (7, 5, dict(flags=0)),
+        (1920, 1080, dict(flags=R.LAMBERT | R.INVERT)), (1280, 720, dict(flags=0)), (64, 64, dict(flags=R.LAMBERT)),
+        (1920, 1080, dict(flags=0)), (1600, 900, dict(flags=R.LAMBERT, spp=2, seed=9)), (7, 5, dict(flags=0)),
+        (1366, 768, dict(flags=R.INVERT | R.RGBA)), (2560, 1440, dict(flags=R.LAMBERT)), (1001, 3, dict(flags=0)),
+        (1920, 1200, dict(flags=R.LAMBERT, spp=3, seed=3)), (1280, 1024, dict(flags=R.INVERT)),
+        (640, 360, dict(flags=R.LAMBERT, spp=5, seed=4)), (3840, 2160, dict(flags=R.LAMBERT | R.INVERT)),
+        (1440, 900, dict(flags=0)),
     ])]
     mixed = [(0.7, 640, 360, dict(flags=R.LAMBERT, ao_rays=8)), (1.9, 800, 600, dict(flags=R.LANE_TRAVERSAL)),
-             (2.2, 512, 512, dict(flags=R.LAMBERT | R.INVERT))]
+             (2.2, 512, 512, dict(flags=R.LAMBERT | R.INVERT)), (2.9, 1280, 720, dict(flags=R.LAMBERT))]
     for jobs, slot in ((shared, 1), (mixed, 2), (shared[:3], R.api.CONTEXT_STREAM)):
         bufs = [torch.zeros(3, h * w, dtype=torch.int32, device="cuda") for (t, w, h, kw) in jobs]
         torch.cuda.synchronize()
