@@ -52,7 +52,7 @@ enum {
     INV_BRUTE_FORCE = 8u, /* test every triangle for every ray instead of traversing the LBVH */
     INV_LANE_TRAVERSAL = 16u, /* one lane per ray with a stack in LDS instead of the tile kernel's candidate lists */
     INV_SPARSE = 32u,     /* with nranks > 1: deal out only the tiles that can contain hits (see inv_sparse_layout) */
-    INV_BLOCKS = 64u,     /* trace 16x16 pixel blocks with a wave per quadrant, as inv_render_batch does, instead of 8x8 tiles whose waves share the candidates: less arithmetic, longer for a draw on its own */
+    INV_BLOCKS = 64u,     /* trace 16x16 pixel blocks with a wave per quadrant, as inv_render_batch does, instead of 8x8 tiles whose waves share the candidates: less arithmetic, longer for a draw on its own, and slow where a block meets hundreds of triangles (its pixels then go through the per-lane traversal) */
 };
 
 /* What the reference fixes as literals or takes from the window: extent (src/invert.cpp:779-791),

@@ -1448,8 +1448,10 @@ static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Ou
     // Blocks do the least arithmetic per pixel but a wave per quadrant is a longer chain of work than a tile's four
     // waves sharing it: a draw on its own is over sooner with tiles (12 against 21 us for the 1080p bunny), several
     // frames sharing a launch get through sooner with blocks (4.0 against 5.1 us per frame).
-    const bool blocks = (batch || (f.flags & INV_BLOCKS)) && f.spp < 4u && per_tile <= 24.0;
-    *mode = per_tile > 48.0 ? kBatched : blocks ? kBlocks : kTiles;
+    // (INV_BLOCKS asks for blocks whatever the frame looks like: always correct, since a block whose lists overflow
+    // hands its pixels to the per-lane traversal, but slow where a block meets hundreds of triangles.)
+    const bool blocks = (f.flags & INV_BLOCKS) || (batch && f.spp < 4u && per_tile <= 24.0);
+    *mode = blocks ? kBlocks : per_tile > 48.0 ? kBatched : kTiles;
     pl.block_px = *mode == kBlocks ? 16u : 8u;
     const uint32_t sh = *mode == kBlocks ? 4u : 3u, e1 = pl.block_px - 1u;
     const uint32_t tiles_x = any ? ((f.rx1 + e1) >> sh) - (f.rx0 >> sh) : 0u;
