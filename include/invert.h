@@ -220,6 +220,9 @@ int inv_deinterleave_sparse(inv_ctx* ctx, const inv_params* params, const uint32
  * buffer (pass INV_RGBA in `flags` if it was rendered with it), little-endian PFM of a depth buffer, and a raw
  * uint32 dump of primitive ids behind a 16-byte header {"PID1", width, height, 0}. */
 int inv_write_ppm(const char* path, const void* color, uint32_t width, uint32_t height, uint32_t flags);
+/* The same buffer as an 8-bit RGBA PNG with an sRGB chunk (the attachment holds sRGB-encoded values); the image data
+ * is stored uncompressed (about 4 bytes per pixel). */
+int inv_write_png(const char* path, const void* color, uint32_t width, uint32_t height, uint32_t flags);
 int inv_write_pfm(const char* path, const float* depth, uint32_t width, uint32_t height);
 int inv_write_primid(const char* path, const uint32_t* primid, uint32_t width, uint32_t height);
 

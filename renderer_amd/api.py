@@ -30,7 +30,7 @@ SYMBOLS = (
     "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
     "inv_render_batch", "inv_render_in_flight", "inv_frame_wait", "inv_frames_join", "inv_frame_stream",
     "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
-    "inv_write_ppm", "inv_write_pfm", "inv_write_primid",
+    "inv_write_ppm", "inv_write_png", "inv_write_pfm", "inv_write_primid",
     "inv_last_error", "inv_version",
 )
 
@@ -81,6 +81,7 @@ def lib():
     L.inv_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_mesh_load_obj_general.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.inv_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.inv_write_pfm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.inv_write_primid.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.inv_mesh_parse_obj.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(vp)]
@@ -217,6 +218,12 @@ def write_ppm(path: str, color: np.ndarray, flags: int = 0) -> None:
     color = np.ascontiguousarray(color, np.uint8)
     h, w = color.shape[:2]
     _chk(lib().inv_write_ppm(os.fsencode(path), color.ctypes.data, w, h, flags))
+
+
+def write_png(path: str, color: np.ndarray, flags: int = 0) -> None:
+    color = np.ascontiguousarray(color, np.uint8)
+    h, w = color.shape[:2]
+    _chk(lib().inv_write_png(os.fsencode(path), color.ctypes.data, w, h, flags))
 
 
 def write_pfm(path: str, depth: np.ndarray) -> None:

@@ -710,6 +710,12 @@ int inv_write_ppm(const char* path, const void* color, uint32_t width, uint32_t 
     return write_ppm(path, (const uint8_t*)color, width, height, (flags & INV_RGBA) != 0);
 }
 
+int inv_write_png(const char* path, const void* color, uint32_t width, uint32_t height, uint32_t flags) try {
+    if (!path || !color || !width || !height) return fail(INV_ERR_ARG, "inv_write_png: null argument or zero extent");
+    return write_png(path, (const uint8_t*)color, width, height, (flags & INV_RGBA) != 0);
+}
+INV_CATCH("inv_write_png")
+
 int inv_write_pfm(const char* path, const float* depth, uint32_t width, uint32_t height) {
     if (!path || !depth || !width || !height) return fail(INV_ERR_ARG, "inv_write_pfm: null argument or zero extent");
     return write_pfm(path, depth, width, height);

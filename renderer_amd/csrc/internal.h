@@ -22,6 +22,7 @@ int parse_obj_text(const char* text, uint64_t size, std::vector<float>& xyzw, st
 // io_extras.cpp
 int parse_obj_general(const char* text, uint64_t size, std::vector<float>& xyzw, std::vector<uint32_t>& idx);
 int write_ppm(const char* path, const uint8_t* color, uint32_t w, uint32_t h, bool rgba_order);
+int write_png(const char* path, const uint8_t* color, uint32_t w, uint32_t h, bool rgba_order);
 int write_pfm(const char* path, const float* depth, uint32_t w, uint32_t h);
 int write_primid(const char* path, const uint32_t* primid, uint32_t w, uint32_t h);
 

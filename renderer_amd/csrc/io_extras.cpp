@@ -116,6 +116,97 @@ int write_ppm(const char* path, const uint8_t* color, uint32_t w, uint32_t h, bo
     return INV_OK;
 }
 
+// PNG (8-bit RGBA, sRGB chunk: the attachment is B8G8R8A8_SRGB, src/invert.cpp:519) of a colour attachment.  The
+// image data is a zlib stream of stored (uncompressed) deflate blocks: valid for every PNG reader, no compressor needed.
+namespace {
+
+struct Crc32 {
+    uint32_t table[256];
+    Crc32() {
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+    }
+    uint32_t update(uint32_t crc, const uint8_t* p, size_t n) const {
+        for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+        return crc;
+    }
+};
+
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)), v.push_back((uint8_t)(x >> 16)), v.push_back((uint8_t)(x >> 8)), v.push_back((uint8_t)x);
+}
+
+bool write_chunk(FILE* fp, const Crc32& crc, const char type[4], const std::vector<uint8_t>& data) {
+    std::vector<uint8_t> head;
+    put_be32(head, (uint32_t)data.size());
+    head.insert(head.end(), type, type + 4);
+    uint32_t c = crc.update(0xFFFFFFFFu, head.data() + 4, 4);
+    c = crc.update(c, data.data(), data.size()) ^ 0xFFFFFFFFu;
+    std::vector<uint8_t> tail;
+    put_be32(tail, c);
+    return std::fwrite(head.data(), 1, head.size(), fp) == head.size() &&
+           (data.empty() || std::fwrite(data.data(), 1, data.size(), fp) == data.size()) &&
+           std::fwrite(tail.data(), 1, 4, fp) == 4;
+}
+
+} // namespace
+
+int write_png(const char* path, const uint8_t* color, uint32_t w, uint32_t h, bool rgba_order) {
+    // one IDAT chunk holds the whole zlib stream: its length field is 32 bits
+    const uint64_t raw = (uint64_t)h * ((uint64_t)w * 4 + 1);
+    if (raw + raw / 65535 * 5 + 64 > 0x7FFFFFFFull) return fail(INV_ERR_ARG, "inv_write_png: image too large for one IDAT chunk");
+    File f(path);
+    if (!f.fp) return fail(INV_ERR_IO, std::string("inv_write_png: cannot open ") + path);
+    static const Crc32 crc;
+    const uint8_t signature[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    bool ok = std::fwrite(signature, 1, 8, f.fp) == 8;
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w), put_be32(ihdr, h);
+    const uint8_t fmt[5] = {8 /* bits */, 6 /* RGBA */, 0, 0, 0};
+    ihdr.insert(ihdr.end(), fmt, fmt + 5);
+    ok = ok && write_chunk(f.fp, crc, "IHDR", ihdr);
+    ok = ok && write_chunk(f.fp, crc, "sRGB", std::vector<uint8_t>{0}); // rendering intent: perceptual
+    // scanlines: filter byte 0, then R,G,B,A
+    std::vector<uint8_t> lines((size_t)raw);
+    uint32_t a = 1, b = 0; // Adler-32 of the uncompressed data
+    for (uint32_t y = 0; y < h; y++) {
+        uint8_t* dst = lines.data() + (size_t)y * ((size_t)w * 4 + 1);
+        const uint8_t* src = color + (size_t)y * w * 4;
+        *dst++ = 0;
+        for (uint32_t x = 0; x < w; x++) {
+            dst[4 * x + 0] = src[4 * x + (rgba_order ? 0 : 2)]; // B,G,R,A memory order unless INV_RGBA
+            dst[4 * x + 1] = src[4 * x + 1];
+            dst[4 * x + 2] = src[4 * x + (rgba_order ? 2 : 0)];
+            dst[4 * x + 3] = src[4 * x + 3];
+        }
+    }
+    for (size_t i = 0; i < lines.size();) { // sums reduced every 4096 bytes: no 32-bit overflow
+        const size_t n = std::min<size_t>(4096, lines.size() - i);
+        for (size_t k = 0; k < n; k++) a += lines[i + k], b += a;
+        a %= 65521u, b %= 65521u, i += n;
+    }
+    std::vector<uint8_t> z;
+    z.reserve(lines.size() + lines.size() / 65535 * 5 + 16);
+    z.push_back(0x78), z.push_back(0x01); // zlib header: deflate, 32 KiB window, no preset dictionary
+    for (size_t i = 0; i < lines.size() || i == 0;) {
+        const size_t n = std::min<size_t>(65535, lines.size() - i);
+        const bool last = i + n >= lines.size();
+        z.push_back(last ? 1 : 0); // stored block
+        z.push_back((uint8_t)n), z.push_back((uint8_t)(n >> 8)), z.push_back((uint8_t)~n), z.push_back((uint8_t)(~n >> 8));
+        z.insert(z.end(), lines.begin() + (std::ptrdiff_t)i, lines.begin() + (std::ptrdiff_t)(i + n));
+        i += n;
+        if (last) break;
+    }
+    put_be32(z, (b << 16) | a);
+    ok = ok && write_chunk(f.fp, crc, "IDAT", z);
+    ok = ok && write_chunk(f.fp, crc, "IEND", std::vector<uint8_t>());
+    if (!ok) return fail(INV_ERR_IO, "inv_write_png: short write");
+    return INV_OK;
+}
+
 // PFM (Pf, little-endian, bottom row first) of a depth attachment.
 int write_pfm(const char* path, const float* depth, uint32_t w, uint32_t h) {
     File f(path);

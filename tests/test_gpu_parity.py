@@ -497,6 +497,8 @@ def test_headless_host_program(oracle, bunny_path, bunny_mesh, tmp_path):
     color, gdepth, gprimid = common.golden_frame("bunny_512")
     assert np.array_equal(rgb, color[..., [2, 1, 0]]) and np.array_equal(primid, gprimid)
     assert np.array_equal(depth.view(np.uint32), gdepth.view(np.uint32))
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(out + ".png")), color[..., [2, 1, 0, 3]])
 
     out = str(tmp_path / "turn")
     w, h, frames = 640, 360, 7

@@ -227,6 +227,15 @@ def test_image_writers(tmp_path):
     assert np.array_equal(rgb, color[..., [2, 1, 0]])  # B,G,R,A in memory -> R,G,B in the file
     api.write_ppm(str(tmp_path / "c2.ppm"), color[..., [2, 1, 0, 3]], flags=R.RGBA)
     assert (tmp_path / "c2.ppm").read_bytes() == raw
+    # PNG: decoded by an independent reader (Pillow), byte for byte R,G,B,A; odd extents and more than one stored block
+    from PIL import Image
+    api.write_png(str(tmp_path / "c.png"), color)
+    img = Image.open(str(tmp_path / "c.png"))
+    assert img.mode == "RGBA" and img.size == (512, 512) and "srgb" in img.info
+    assert np.array_equal(np.asarray(img), color[..., [2, 1, 0, 3]])
+    small = np.arange(7 * 5 * 4, dtype=np.uint8).reshape(5, 7, 4)
+    api.write_png(str(tmp_path / "s.png"), small, flags=R.RGBA)
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "s.png"))), small)
     raw = (tmp_path / "d.pfm").read_bytes()
     head = b"Pf\n512 512\n-1.0\n"
     assert raw.startswith(head)

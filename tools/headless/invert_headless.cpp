@@ -144,6 +144,7 @@ int main(int argc, char** argv) {
     for (uint32_t p : primid) hits += p != 0xFFFFFFFFu;
     if (!out_prefix.empty()) {
         if (inv_write_ppm((out_prefix + ".ppm").c_str(), color.data(), width, height, flags) != INV_OK ||
+            inv_write_png((out_prefix + ".png").c_str(), color.data(), width, height, flags) != INV_OK ||
             inv_write_pfm((out_prefix + ".pfm").c_str(), depth.data(), width, height) != INV_OK ||
             inv_write_primid((out_prefix + ".pid").c_str(), primid.data(), width, height) != INV_OK)
             return die("writing the attachments");

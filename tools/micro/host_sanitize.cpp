@@ -117,6 +117,8 @@ int main(int argc, char** argv) {
     std::vector<float> depth(33 * 17, 0.5f);
     std::vector<uint32_t> prim(33 * 17, 7);
     EXPECT(inv_write_ppm("/tmp/host_sanitize.ppm", color.data(), 33, 17, 0) == INV_OK);
+    EXPECT(inv_write_png("/tmp/host_sanitize.png", color.data(), 33, 17, 0) == INV_OK);
+    EXPECT(inv_write_png("/tmp/host_sanitize.png", color.data(), 33, 17, INV_RGBA) == INV_OK);
     EXPECT(inv_write_pfm("/tmp/host_sanitize.pfm", depth.data(), 33, 17) == INV_OK);
     EXPECT(inv_write_primid("/tmp/host_sanitize.pid", prim.data(), 33, 17) == INV_OK);
     EXPECT(inv_write_ppm("/nonexistent-dir/x.ppm", color.data(), 33, 17, 0) == INV_ERR_IO);
