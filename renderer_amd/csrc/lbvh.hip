@@ -310,7 +310,7 @@ __device__ __forceinline__ int delta(const uint64_t* __restrict__ m, uint32_t n,
 
 __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, uint32_t n,
                                                 uint32_t* __restrict__ child, uint32_t* __restrict__ parent,
-                                                uint32_t* __restrict__ leaf_parent, float* __restrict__ nodes) {
+                                                uint32_t* __restrict__ leaf_parent, uint2* __restrict__ range) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n - 1) return;
     if (i == 0) parent[0] = 0xFFFFFFFFu;
@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
     }
     child[2 * i] = c0;
     child[2 * i + 1] = c1;
-    // sorted leaves covered by this node: [lo, hi]; child 0 covers [lo, gamma], child 1 [gamma + 1, hi]
-    nodes[16 * i + 14] = __uint_as_float((uint32_t)lo);
-    nodes[16 * i + 15] = __uint_as_float((uint32_t)hi);
+    // sorted leaves covered by this node: [lo, hi]; child 0 covers [lo, gamma], child 1 [gamma + 1, hi].  Kept in an
+    // array of its own: the refit writes them with the rest of the node's 64-byte record, in one piece
+    range[i] = make_uint2((uint32_t)lo, (uint32_t)hi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
 //    its second child arrived, so every box a launch reads was written by an earlier launch and no
 //    data is handed between workgroups inside a launch; only the arrival counters are shared.
 //    Node i (16 floats): child0 lo xyz, hi xyz, child1 lo xyz, hi xyz, child0, child1, first and
-//    last sorted leaf under the node (written by the hierarchy kernel).  union_box[i] (8 floats)
+//    last sorted leaf under the node (from the hierarchy kernel's range array).  union_box[i] (8 floats)
 //    carries the node's own box and height upwards.
 // ------------------------------------------------------------------------------------------
 // Appends the flagged lanes' values to a list in global memory.  The list's counter is one address for the whole
@@ -387,19 +387,100 @@ __device__ __forceinline__ void block_append(bool flag, uint32_t value, uint32_t
     __syncthreads(); // the next call overwrites s_wave
 }
 
-// The leaves' arrivals need no atomics: how many of a node's children are leaves is in its child references.
-// Sets every arrival counter to that number and lists the nodes over two leaves as the first level.
-__global__ __launch_bounds__(1024) void k_refit_leaves(uint32_t ninternal, const uint32_t* __restrict__ child,
-                                                       uint32_t* __restrict__ arrive, uint32_t* __restrict__ next,
-                                                       uint32_t* __restrict__ next_count) {
-    const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t leaves = 0;
-    if (node < ninternal) {
-        const uint2 c = ((const uint2*)child)[node];
-        leaves = (c.x >> 31) + (c.y >> 31);
-        arrive[node] = leaves;
+// First the part of the tree that needs no exchange between workgroups.  Internal node i covers a range of sorted
+// leaves that contains leaf i, so every node whose range lies inside one chunk of kChunk consecutive leaves has its
+// index, its leaves and all of its descendants inside that chunk: one workgroup per chunk finishes those nodes in
+// LDS, sweep by sweep (a node is finished in the sweep after the one that finished its later child, so the sweep
+// number is the node's height).  What remains are the nodes whose range crosses a chunk boundary (a root-to-leaf path
+// per boundary); the workgroup that owns such a node's index sets its arrival counter to the number of children that
+// are already complete (leaves, and nodes finished inside a chunk) and lists it for the first launch per level if
+// both are.
+constexpr uint32_t kChunk = 1024;
+constexpr uint32_t kOpen = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                         const float4* __restrict__ TC, const uint32_t* __restrict__ child,
+                                                         const uint2* __restrict__ range, uint32_t n,
+                                                         float* __restrict__ union_box,
+                                                         float* __restrict__ nodes, uint32_t* __restrict__ arrive,
+                                                         uint32_t* __restrict__ next, uint32_t* __restrict__ next_count,
+                                                         uint32_t* __restrict__ finished_count) {
+    __shared__ float s_leaf[6][kChunk]; // boxes of the chunk's leaves
+    __shared__ float s_box[6][kChunk];  // boxes of the internal nodes finished here
+    __shared__ uint32_t s_sweep[kChunk]; // sweep that finished the node, kOpen while it waits
+    const uint32_t t = threadIdx.x, base = blockIdx.x * kChunk, i = base + t;
+    if (i < n) {
+        float lo[3], hi[3];
+        tri_box(TA[i], TB[i], TC[i], lo, hi);
+#pragma unroll
+        for (int a = 0; a < 3; a++) s_leaf[a][t] = lo[a], s_leaf[3 + a][t] = hi[a];
     }
-    block_append<1024>(leaves == 2u, node, next, next_count);
+    const bool valid = i + 1u < n;
+    uint32_t c0 = 0, c1 = 0;
+    if (valid) {
+        const uint2 c = ((const uint2*)child)[i];
+        c0 = c.x, c1 = c.y;
+    }
+    s_sweep[t] = kOpen;
+    const bool leaf0 = (c0 >> 31) != 0u, leaf1 = (c1 >> 31) != 0u;
+    const uint32_t k0 = (c0 & 0x7FFFFFFFu) - base, k1 = (c1 & 0x7FFFFFFFu) - base; // >= kChunk: in another chunk
+    bool open = valid && k0 < kChunk && k1 < kChunk;
+    uint2 leaves = make_uint2(0u, 0u);
+    if (valid) leaves = range[i];
+    float b0[6], b1[6], u[6];
+    uint32_t height = kOpen;
+    __syncthreads();
+    for (uint32_t sweep = 1;; sweep++) {
+        bool did = false;
+        // a child finished in this very sweep reads as kOpen or as `sweep`: not ready either way, and its box is
+        // not looked at before the barrier below
+        if (open && (leaf0 || s_sweep[k0] < sweep) && (leaf1 || s_sweep[k1] < sweep)) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                b0[a] = leaf0 ? s_leaf[a][k0] : s_box[a][k0];
+                b1[a] = leaf1 ? s_leaf[a][k1] : s_box[a][k1];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) u[a] = fminf(b0[a], b1[a]), u[3 + a] = fmaxf(b0[3 + a], b1[3 + a]);
+#pragma unroll
+            for (int a = 0; a < 6; a++) s_box[a][t] = u[a];
+            s_sweep[t] = height = sweep;
+            open = false, did = true;
+        }
+        if (!__syncthreads_or(did)) break;
+    }
+    // the finished nodes' records, all at once: neighbouring lanes write neighbouring 64-byte records, each whole
+    if (height != kOpen) {
+        float4* nd = (float4*)nodes + 4 * (size_t)i;
+        nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+        nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+        nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+        nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
+        float4* ub = (float4*)union_box + 2 * (size_t)i;
+        ub[0] = make_float4(u[0], u[1], u[2], u[3]);
+        ub[1] = make_float4(u[4], u[5], __uint_as_float(height), 0.0f);
+    }
+    const bool crossing = valid && height == kOpen;
+    uint32_t arrived = 0;
+    if (crossing) {
+        const uint32_t cs[2] = {c0, c1};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t c = cs[k];
+            if (c >> 31) {
+                arrived++; // a leaf: the launches per level read its triangle themselves
+            } else if (c - base < kChunk) {
+                arrived += s_sweep[c - base] != kOpen;
+            } else { // a node of another chunk: finished there if its leaves are all in that chunk
+                const uint2 r = range[c];
+                arrived += r.x / kChunk == r.y / kChunk;
+            }
+        }
+        arrive[i] = arrived;
+    }
+    const uint32_t finished = (uint32_t)__syncthreads_count(valid && !crossing);
+    if (t == 0 && finished) atomicAdd(finished_count, finished);
+    block_append<(int)kChunk>(crossing && arrived == 2u, i, next, next_count);
 }
 
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
@@ -419,9 +500,11 @@ __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restr
 // Finishes one internal node (both children are complete); returns its parent.
 __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                const float4* __restrict__ TC, const uint32_t* __restrict__ child,
-                                               const uint32_t* __restrict__ parent, uint32_t node,
+                                               const uint32_t* __restrict__ parent,
+                                               const uint2* __restrict__ range, uint32_t node,
                                                float* __restrict__ union_box, float* __restrict__ nodes) {
     const uint32_t c0 = child[2 * (size_t)node], c1 = child[2 * (size_t)node + 1];
+    const uint2 leaves = range[node];
     float l0[3], h0[3], l1[3], h1[3];
     uint32_t ht0, ht1;
     load_child_box(c0, TA, TB, TC, union_box, l0, h0, ht0);
@@ -431,8 +514,7 @@ __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, co
     nd[0] = make_float4(l0[0], l0[1], l0[2], h0[0]);
     nd[1] = make_float4(h0[1], h0[2], l1[0], l1[1]);
     nd[2] = make_float4(l1[2], h1[0], h1[1], h1[2]);
-    nodes[16 * (size_t)node + 12] = __uint_as_float(c0);
-    nodes[16 * (size_t)node + 13] = __uint_as_float(c1);
+    nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
     float4* u = (float4*)union_box + 2 * (size_t)node;
     u[0] = make_float4(fminf(l0[0], l1[0]), fminf(l0[1], l1[1]), fminf(l0[2], l1[2]), fmaxf(h0[0], h1[0]));
     u[1] = make_float4(fmaxf(h0[1], h1[1]), fmaxf(h0[2], h1[2]), __uint_as_float(ht), 0.0f);
@@ -442,6 +524,7 @@ __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, co
 __global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                      const float4* __restrict__ TC, const uint32_t* __restrict__ child,
                                                      const uint32_t* __restrict__ parent,
+                                                     const uint2* __restrict__ range,
                                                      const uint32_t* __restrict__ ready,
                                                      const uint32_t* __restrict__ ready_count,
                                                      uint32_t* __restrict__ arrive, float* __restrict__ union_box,
@@ -452,7 +535,7 @@ __global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ 
     for (uint32_t base = blockIdx.x * blockDim.x; base < nready; base += gridDim.x * blockDim.x) { // block-uniform
         const uint32_t q = base + threadIdx.x;
         uint32_t up = 0xFFFFFFFFu;
-        if (q < nready) up = refit_node(TA, TB, TC, child, parent, ready[q], union_box, nodes);
+        if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes);
         // the second child to arrive makes the parent ready for the next launch
         const bool second = up != 0xFFFFFFFFu && atomicAdd(&arrive[up], 1u) == 1u;
         block_append<256>(second, up, next, next_count);
@@ -592,7 +675,7 @@ size_t lbvh_scratch_bytes(uint32_t n) {
     const size_t ntiles = sort_tiles_for(n);
     const size_t sizes[] = {(size_t)bounds_blocks_for(n) * 24, 32, (size_t)n * 8, (size_t)n * 4, ntiles * 256 * 4,
                             (size_t)(n - 1) * 4, (ntiles * 256 / kScanBlock + 2) * 4, (size_t)(n - 1) * 4,
-                            (size_t)(n - 1) * 4, (kMaxLevels + 1) * 4, (size_t)(n - 1) * 32, 16};
+                            (size_t)(n - 1) * 4, (kMaxLevels + 2) * 4, (size_t)(n - 1) * 32, (size_t)(n - 1) * 8, 16};
     size_t total = 0;
     for (size_t b : sizes) total += Arena::aligned(b);
     return total;
@@ -613,8 +696,9 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     uint32_t* arrive = tmp.take<uint32_t>((size_t)(n - 1) * 4);
     uint32_t* scan_totals = tmp.take<uint32_t>(((size_t)ntiles * 256 / kScanBlock + 2) * 4);
     uint32_t* ready[2] = {tmp.take<uint32_t>((size_t)(n - 1) * 4), tmp.take<uint32_t>((size_t)(n - 1) * 4)};
-    uint32_t* ready_count = tmp.take<uint32_t>((kMaxLevels + 1) * 4); // one counter per tree level
+    uint32_t* ready_count = tmp.take<uint32_t>((kMaxLevels + 2) * 4); // one counter per tree level, one for the chunks
     float* union_box = tmp.take<float>((size_t)(n - 1) * 32);
+    uint2* range = tmp.take<uint2>((size_t)(n - 1) * 8);
     uint32_t* d_ncut = tmp.take<uint32_t>(16);
     // what the scene keeps
     sc.morton = keep.take<uint64_t>((size_t)n * 8);
@@ -657,29 +741,33 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     }
     hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, A0, B0, C0, sc.order, n, A1, B1, C1);
     hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
-                       sc.nodes);
-    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 1) * 4, s));
-    hipLaunchKernelGGL(k_refit_leaves, dim3((n - 1 + 1023) / 1024), dim3(1024), 0, s, n - 1, sc.child, arrive, ready[0],
-                       ready_count);
+                       range);
+    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2) * 4, s));
+    uint32_t* finished_in_chunks = ready_count + kMaxLevels + 1;
+    const uint32_t nchunks = (n + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, (const float4*)A1, (const float4*)B1,
+                       (const float4*)C1, sc.child, range, n, union_box, sc.nodes, arrive, ready[0], ready_count,
+                       finished_in_chunks);
     HIP_RET(hipGetLastError());
-    // One launch per tree level; level L reads its size from ready_count[L] on the device and appends the nodes that
-    // become ready to level L + 1.  The host queues eight levels at a time and then looks at the counters.
-    const dim3 grid_level(std::min<uint32_t>((n + 255) / 256, 2048));
-    uint32_t level_count[kMaxLevels + 1];
+    // The nodes that cross chunk boundaries: one launch per tree level; level L reads its size from ready_count[L] on
+    // the device and appends the nodes that become ready to level L + 1.  The host queues sixteen levels at a time
+    // (an empty launch costs a twentieth of a look) and then looks at the counters.
+    const dim3 grid_level(std::min<uint32_t>(nchunks, 2048));
+    uint32_t level_count[kMaxLevels + 2] = {0};
     uint32_t level = 0;
     for (;;) {
-        for (int i = 0; i < 8 && level < kMaxLevels; i++, level++) {
+        for (int i = 0; nchunks > 1 && i < 16 && level < kMaxLevels; i++, level++) {
             const int cur = (int)(level & 1u);
             hipLaunchKernelGGL(k_refit_level, grid_level, blk, 0, s, (const float4*)A1, (const float4*)B1,
-                               (const float4*)C1, sc.child, sc.parent, ready[cur], ready_count + level, arrive, union_box,
+                               (const float4*)C1, sc.child, sc.parent, range, ready[cur], ready_count + level, arrive, union_box,
                                sc.nodes, ready[cur ^ 1], ready_count + level + 1);
         }
-        HIP_RET(hipMemcpyAsync(level_count, ready_count, (level + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIP_RET(hipMemcpyAsync(level_count, ready_count, (kMaxLevels + 2) * 4, hipMemcpyDeviceToHost, s));
         HIP_RET(hipStreamSynchronize(s));
         if (level_count[level] == 0) break; // nothing is waiting for another level
         if (level >= kMaxLevels) return hipErrorUnknown; // a tree over 63+32-bit keys is at most 96 levels deep
     }
-    uint64_t finished = 0;
+    uint64_t finished = level_count[kMaxLevels + 1];
     for (uint32_t l = 0; l < level; l++) finished += level_count[l];
     if (finished != n - 1) return hipErrorUnknown; // every internal node must have been refitted
     HIP_RET(hipGetLastError());
