@@ -85,6 +85,11 @@ typedef struct inv_outputs {
 int inv_ctx_create(int device, void* hip_stream, inv_ctx** out);
 int inv_ctx_destroy(inv_ctx* ctx);
 int inv_ctx_synchronize(inv_ctx* ctx);
+/* A context keeps the device memory its last scene build needed only while it ran (about 120 bytes per triangle),
+ * so that the next build does not allocate it again: the counterpart of the staging buffer transferData creates and
+ * destroys on every call, with the TODO to keep it (src/invert.cpp:991-992, 1000-1032, 1078-1079).  This call
+ * releases it; inv_ctx_destroy does too. */
+int inv_ctx_trim(inv_ctx* ctx);
 
 /* ---- mesh: struct Obj ------------------------------------------------------------------------------------ */
 /* Obj::Obj(const char*) (src/invert.cpp:42-209): same fixed text format, same float32 arithmetic, so the

@@ -22,7 +22,7 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEV
 
 # every symbol include/invert.h declares
 SYMBOLS = (
-    "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize",
+    "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize", "inv_ctx_trim",
     "inv_mesh_load_obj", "inv_mesh_load_obj_general", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
     "inv_mesh_indices", "inv_mesh_pin", "inv_mesh_destroy",
     "inv_camera_reference", "inv_camera_turntable",
@@ -78,6 +78,7 @@ def lib():
     L.inv_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.inv_ctx_destroy.argtypes = [vp]
     L.inv_ctx_synchronize.argtypes = [vp]
+    L.inv_ctx_trim.argtypes = [vp]
     L.inv_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_mesh_load_obj_general.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -249,6 +250,10 @@ class Context:
 
     def synchronize(self):
         _chk(lib().inv_ctx_synchronize(self._h))
+
+    def trim(self):
+        """Release the device memory kept from the last scene build for the next one."""
+        _chk(lib().inv_ctx_trim(self._h))
 
     def frame_wait(self, slot: int):
         """Block until every draw enqueued on frame slot `slot` has finished (the reference's fence wait)."""

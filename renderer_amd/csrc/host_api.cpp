@@ -47,6 +47,10 @@ struct inv_ctx {
     // frame slots (created on first use): a stream each, and an event the join records on it
     hipStream_t flight[INV_MAX_FRAMES_IN_FLIGHT] = {};
     hipEvent_t flight_done[INV_MAX_FRAMES_IN_FLIGHT] = {};
+
+    // what a scene build needs only while it runs; kept for the next build of this context (inv_ctx_trim frees it)
+    void* build_scratch = nullptr;
+    size_t build_scratch_bytes = 0;
 };
 
 struct inv_mesh {
@@ -194,8 +198,20 @@ int inv_ctx_destroy(inv_ctx* ctx) {
         if (ctx->flight[i]) (void)hipStreamSynchronize(ctx->flight[i]), (void)hipStreamDestroy(ctx->flight[i]);
         if (ctx->flight_done[i]) (void)hipEventDestroy(ctx->flight_done[i]);
     }
+    if (ctx->build_scratch) (void)hipFree(ctx->build_scratch);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return INV_OK;
+}
+
+int inv_ctx_trim(inv_ctx* ctx) {
+    if (!ctx) return fail(INV_ERR_ARG, "inv_ctx_trim: ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->build_scratch) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->build_scratch));
+    }
+    ctx->build_scratch = nullptr, ctx->build_scratch_bytes = 0;
     return INV_OK;
 }
 
@@ -349,7 +365,8 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     DeviceScene& d = s->d;
     d.nv = nv;
     d.ntri = (uint32_t)ntri64;
-    // Two device allocations per build: what the scene keeps, and what only the build needs.
+    // Two device allocations: what the scene keeps, and what only the build needs (the context keeps the latter for
+    // its next build: allocating and freeing half a gigabyte costs as much as a tenth of a five-million-triangle build).
     const size_t tri_bytes = Arena::aligned((size_t)d.ntri * 16);
     const bool tree = d.ntri >= 2;
     Arena keep, scratch;
@@ -361,14 +378,19 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     auto bail = [&](hipError_t err, const char* what) {
         rc = hip_fail(err, what);
         (void)hipStreamSynchronize(ctx->stream);
-        if (scratch.base) (void)hipFree(scratch.base);
         free_device_scene(d);
         delete s;
         return rc;
     };
     if ((e = hipMalloc((void**)&keep.base, keep.size)) != hipSuccess) return bail(e, "hipMalloc(scene)");
     d.arena = keep.base;
-    if ((e = hipMalloc((void**)&scratch.base, scratch.size)) != hipSuccess) return bail(e, "hipMalloc(build scratch)");
+    if (ctx->build_scratch_bytes < scratch.size) {
+        if (ctx->build_scratch) (void)hipFree(ctx->build_scratch); // no build is running: every build ends with a sync
+        ctx->build_scratch = nullptr, ctx->build_scratch_bytes = 0;
+        if ((e = hipMalloc(&ctx->build_scratch, scratch.size)) != hipSuccess) return bail(e, "hipMalloc(build scratch)");
+        ctx->build_scratch_bytes = scratch.size;
+    }
+    scratch.base = (char*)ctx->build_scratch;
     // The Obj arrays go up first (src/invert.cpp:1136-1140, 1161-1164).  From a pinned mesh (inv_mesh_pin: the
     // host-visible staging buffer of transferData, src/invert.cpp:993-1082) the copies are DMA straight out of the
     // arrays and these calls return at once; the context's stream keeps them in order with the build's kernels.
@@ -431,7 +453,6 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         if ((e = build_lbvh(ctx->stream, d, keep, scratch, A0, B0, C0)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
-    (void)hipFree(scratch.base);
     *out = s;
     return INV_OK;
 }

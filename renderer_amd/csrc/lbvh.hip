@@ -5,6 +5,8 @@
 // The build is deterministic: every float that ends up in a node is a min/max of input floats,
 // the sort is stable and the hierarchy depends only on the sorted keys, so the tree is identical
 // on every rank and equal to a sequential restatement of the same steps.
+#include <cstring>
+
 #include "internal.h"
 #include "rt_core.h"
 
@@ -574,11 +576,28 @@ __device__ __forceinline__ uint32_t block_ranks(bool f0, bool f1, uint32_t (*tot
     return all0 + all1;
 }
 
+// The host queues this kernel behind the refit launches without knowing whether they were enough: `pending` is the
+// size of the level after the last one queued, and while that is not zero the node records are not complete and
+// nothing is read.  summary: [0] number of cut records (kCutUnfinished: refit not finished), [1..6] scene bounds,
+// [7] height of the root -- everything the host wants to know at the end of a build, in one place.
+constexpr uint32_t kCutUnfinished = 0xFFFFFFFFu;
+constexpr uint32_t kSummaryWords = 8;
+
 __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restrict__ nodes, float* __restrict__ cut,
-                                                          float* __restrict__ groups, uint32_t* __restrict__ ncut_out) {
+                                                          float* __restrict__ groups,
+                                                          const uint32_t* __restrict__ pending,
+                                                          const float* __restrict__ bbox,
+                                                          const float* __restrict__ union_box,
+                                                          uint32_t* __restrict__ summary) {
     __shared__ uint32_t frontier[2][kCutCap]; // (parent << 1) | side
     __shared__ uint32_t tot[2][kCutThreads / 64];
     const uint32_t tid = threadIdx.x;
+    if (*pending != 0u) { // block-uniform
+        if (tid == 0) summary[0] = kCutUnfinished;
+        return;
+    }
+    if (tid < 6) summary[1 + tid] = __float_as_uint(bbox[tid]);
+    if (tid == 6) summary[7] = __float_as_uint(union_box[6]);
     if (tid == 0) frontier[0][0] = 0u, frontier[0][1] = 1u; // the root's two sides
     uint32_t nf = 2, nout = 0; // block-uniform
     int cur = 0;
@@ -634,7 +653,7 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
         cur ^= 1;
         __syncthreads();
     }
-    if (tid == 0) *ncut_out = nout;
+    if (tid == 0) summary[0] = nout;
     __threadfence_block();
     __syncthreads(); // the records are read back below by other lanes of this workgroup
     // boxes of kCutGroup consecutive records (breadth-first order keeps neighbours together): 8 floats per group
@@ -675,7 +694,7 @@ size_t lbvh_scratch_bytes(uint32_t n) {
     const size_t ntiles = sort_tiles_for(n);
     const size_t sizes[] = {(size_t)bounds_blocks_for(n) * 24, 32, (size_t)n * 8, (size_t)n * 4, ntiles * 256 * 4,
                             (size_t)(n - 1) * 4, (ntiles * 256 / kScanBlock + 2) * 4, (size_t)(n - 1) * 4,
-                            (size_t)(n - 1) * 4, (kMaxLevels + 2) * 4, (size_t)(n - 1) * 32, (size_t)(n - 1) * 8, 16};
+                            (size_t)(n - 1) * 4, (kMaxLevels + 2 + kSummaryWords) * 4, (size_t)(n - 1) * 32, (size_t)(n - 1) * 8};
     size_t total = 0;
     for (size_t b : sizes) total += Arena::aligned(b);
     return total;
@@ -696,10 +715,10 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     uint32_t* arrive = tmp.take<uint32_t>((size_t)(n - 1) * 4);
     uint32_t* scan_totals = tmp.take<uint32_t>(((size_t)ntiles * 256 / kScanBlock + 2) * 4);
     uint32_t* ready[2] = {tmp.take<uint32_t>((size_t)(n - 1) * 4), tmp.take<uint32_t>((size_t)(n - 1) * 4)};
-    uint32_t* ready_count = tmp.take<uint32_t>((kMaxLevels + 2) * 4); // one counter per tree level, one for the chunks
+    // one counter per tree level, one for the chunks, and the build's summary behind them (one copy fetches it all)
+    uint32_t* ready_count = tmp.take<uint32_t>((kMaxLevels + 2 + kSummaryWords) * 4);
     float* union_box = tmp.take<float>((size_t)(n - 1) * 32);
     uint2* range = tmp.take<uint2>((size_t)(n - 1) * 8);
-    uint32_t* d_ncut = tmp.take<uint32_t>(16);
     // what the scene keeps
     sc.morton = keep.take<uint64_t>((size_t)n * 8);
     sc.order = keep.take<uint32_t>((size_t)n * 4);
@@ -709,7 +728,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     sc.nodes = keep.take<float>((size_t)(n - 1) * 64);
     sc.cut = keep.take<float>((size_t)kCutCap * 32);
     sc.cut_groups = keep.take<float>((size_t)(kCutCap / kCutGroup) * 32);
-    if (!d_ncut || !sc.cut_groups) return hipErrorOutOfMemory; // the arenas were sized for something else
+    if (!range || !sc.cut_groups) return hipErrorOutOfMemory; // the arenas were sized for something else
     float4 *A1 = (float4*)sc.triA, *B1 = (float4*)sc.triB, *C1 = (float4*)sc.triC;
 
     const float4 *A0 = (const float4*)A0f, *B0 = (const float4*)B0f, *C0 = (const float4*)C0f;
@@ -742,7 +761,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, A0, B0, C0, sc.order, n, A1, B1, C1);
     hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
-    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2) * 4, s));
+    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
     uint32_t* finished_in_chunks = ready_count + kMaxLevels + 1;
     const uint32_t nchunks = (n + kChunk - 1) / kChunk;
     hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, (const float4*)A1, (const float4*)B1,
@@ -750,34 +769,40 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
                        finished_in_chunks);
     HIP_RET(hipGetLastError());
     // The nodes that cross chunk boundaries: one launch per tree level; level L reads its size from ready_count[L] on
-    // the device and appends the nodes that become ready to level L + 1.  The host queues sixteen levels at a time
-    // (an empty launch costs a twentieth of a look) and then looks at the counters.
+    // the device and appends the nodes that become ready to level L + 1.  The host does not know the tree's height:
+    // it queues as many levels as a tree of this size usually has and the cut kernel behind them (an empty launch
+    // costs a twentieth of a look at the counters), then looks once; the rare deeper tree gets sixteen more levels
+    // and another cut.
     const dim3 grid_level(std::min<uint32_t>(nchunks, 2048));
-    uint32_t level_count[kMaxLevels + 2] = {0};
-    uint32_t level = 0;
+    uint32_t host_words[kMaxLevels + 2 + kSummaryWords] = {0};
+    const uint32_t* level_count = host_words;
+    const uint32_t* summary = host_words + kMaxLevels + 2;
+    uint32_t log2n = 0;
+    while ((1ull << log2n) < n) log2n++;
+    uint32_t level = 0, want = nchunks > 1 ? std::min<uint32_t>(kMaxLevels, log2n + 14u) : 0u;
     for (;;) {
-        for (int i = 0; nchunks > 1 && i < 16 && level < kMaxLevels; i++, level++) {
+        for (; level < want; level++) {
             const int cur = (int)(level & 1u);
             hipLaunchKernelGGL(k_refit_level, grid_level, blk, 0, s, (const float4*)A1, (const float4*)B1,
                                (const float4*)C1, sc.child, sc.parent, range, ready[cur], ready_count + level, arrive, union_box,
                                sc.nodes, ready[cur ^ 1], ready_count + level + 1);
         }
-        HIP_RET(hipMemcpyAsync(level_count, ready_count, (kMaxLevels + 2) * 4, hipMemcpyDeviceToHost, s));
-        HIP_RET(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
+                           (const uint32_t*)(ready_count + level), (const float*)d_bbox, (const float*)union_box,
+                           ready_count + kMaxLevels + 2);
+        HIP_RET(hipGetLastError());
+        HIP_RET(hipMemcpyAsync(host_words, ready_count, sizeof host_words, hipMemcpyDeviceToHost, s));
+        HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
         if (level_count[level] == 0) break; // nothing is waiting for another level
         if (level >= kMaxLevels) return hipErrorUnknown; // a tree over 63+32-bit keys is at most 96 levels deep
+        want = std::min<uint32_t>(kMaxLevels, level + 16u);
     }
     uint64_t finished = level_count[kMaxLevels + 1];
     for (uint32_t l = 0; l < level; l++) finished += level_count[l];
-    if (finished != n - 1) return hipErrorUnknown; // every internal node must have been refitted
-    HIP_RET(hipGetLastError());
-    hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
-                       d_ncut);
-    HIP_RET(hipGetLastError());
-    HIP_RET(hipMemcpyAsync(&sc.ncut, d_ncut, 4, hipMemcpyDeviceToHost, s));
-    HIP_RET(hipMemcpyAsync(sc.bbox, d_bbox, 24, hipMemcpyDeviceToHost, s));
-    HIP_RET(hipMemcpyAsync(&sc.height, union_box + 6, 4, hipMemcpyDeviceToHost, s)); // root height
-    HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
+    if (finished != n - 1 || summary[0] == kCutUnfinished) return hipErrorUnknown; // every internal node must have been refitted
+    sc.ncut = summary[0];
+    std::memcpy(sc.bbox, summary + 1, 24);
+    sc.height = summary[7];
     sc.has_bvh = true;
     return hipSuccess;
 }

@@ -465,6 +465,39 @@ def test_pinned_mesh_builds_the_same_scene(gpu_ctx, bunny_path):
     empty.close()
 
 
+def test_build_scratch_is_kept_grown_and_trimmed(oracle, gpu_ctx, bunny_mesh):
+    """A context keeps the memory a build needs only while it runs: builds of growing and shrinking size, with the
+    memory released in between, give the same scenes as ever (a smaller build runs inside the larger one's memory)."""
+    xyzw, idx = bunny_mesh
+    mesh = R.Mesh.from_arrays(xyzw, idx)
+    small = R.Mesh.from_arrays(xyzw, idx[:3 * 700])
+    tr = common.grid_translations(3)
+    cam, prm = R.camera_reference(512, 512), R.make_params(512, 512)
+    want_small = oracle.render_bvh(xyzw, idx[:3 * 700], oracle.camera_reference(512, 512), _oracle_params(oracle, prm))
+    far = common.pulled_back_camera(R.camera_reference(320, 200), 0.27 * 3)
+    fx, fi = common.flatten_instances(xyzw, idx, tr)
+    prm_far = R.make_params(320, 200)
+    want_grid = oracle.render_bvh(fx, fi, oracle.Camera.from_buffer_copy(bytes(far)), _oracle_params(oracle, prm_far))
+    gpu_ctx.trim()  # nothing kept yet, or whatever an earlier test left
+    for step in ("small", "bunny", "grid", "small", "trim", "bunny", "grid"):
+        if step == "trim":
+            gpu_ctx.trim()
+            gpu_ctx.trim()  # twice is fine
+            continue
+        if step == "grid":
+            scene = R.Scene(gpu_ctx, mesh, translations=tr)
+            common.assert_frames_equal(scene.render(far, prm_far), want_grid, step)
+        elif step == "small":
+            scene = R.Scene(gpu_ctx, small)
+            common.assert_frames_equal(scene.render(cam, prm), want_small, step)
+        else:
+            scene = R.Scene(gpu_ctx, mesh)
+            common.assert_frames_equal(scene.render(cam, prm), common.golden_frame("bunny_512"), step)
+        scene.close()
+    mesh.close()
+    small.close()
+
+
 def test_headless_host_program(oracle, bunny_path, bunny_mesh, tmp_path):
     """tools/headless/invert_headless (C++ on the C ABI: load, build, frame loop with frames in flight, attachments
     written out): the files of the last frame against the golden (parity mode) and the oracle (turntable)."""

@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--side", type=int, default=32)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--builds", type=int, default=8)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     a = ap.parse_args()
@@ -34,15 +35,17 @@ def main():
     ctx = R.Context(0, stream=stream.cuda_stream)
     mesh = R.Mesh.load_obj(objfmt.bunny_obj_path())
     tr = common.grid_translations(a.side)
-    for rep in range(3):
+    times = []
+    for rep in range(a.builds):
         t0 = time.perf_counter()
         scene = R.Scene(ctx, mesh, translations=tr)
-        dt = time.perf_counter() - t0
+        times.append((time.perf_counter() - t0) * 1e3)
         ntri, nnodes, nbytes = scene.counts()
-        print("build %d: %d triangles, %.1f MB scene, %.2f ms (host wall, includes upload and the final sync)"
-              % (rep, ntri, nbytes / 1e6, dt * 1e3))
-        if rep < 2:
+        if rep < a.builds - 1:
             scene.close()
+    print("build: %d triangles, %.1f MB scene; host wall including upload and the final sync: first %.2f ms, then "
+          "median %.2f ms, min %.2f ms over %d builds" % (ntri, nbytes / 1e6, times[0], float(np.median(times[1:])),
+                                                          min(times[1:]), len(times) - 1))
     cam = common.pulled_back_camera(R.camera_reference(w, h), 0.27 * a.side)
     buf = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
     for name, flags in (("tile kernel (auto)", 0), ("lane traversal", R.LANE_TRAVERSAL)):

@@ -126,6 +126,7 @@ int main(int argc, char** argv) {
     EXPECT(inv_render(nullptr, nullptr, nullptr, nullptr) == INV_ERR_ARG);
     EXPECT(inv_render_batch(nullptr, 0, 0, nullptr, nullptr, nullptr) == INV_ERR_ARG);
     EXPECT(inv_frame_wait(nullptr, 0) == INV_ERR_ARG && inv_frames_join(nullptr) == INV_ERR_ARG);
+    EXPECT(inv_ctx_trim(nullptr) == INV_ERR_ARG);
     inv_ctx* ctx = nullptr;
     const int rc = inv_ctx_create(0, nullptr, &ctx); // INV_ERR_NO_DEVICE here, INV_OK on a GPU box
     EXPECT(rc == INV_OK || rc == INV_ERR_NO_DEVICE);
