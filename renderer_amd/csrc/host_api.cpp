@@ -372,7 +372,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     Arena keep, scratch;
     keep.size = Arena::aligned((size_t)nv * 16) + Arena::aligned((size_t)base_ntri * 12) + 3 * tri_bytes +
                 lbvh_keep_bytes(d.ntri) + 256;
-    scratch.size = (tree ? 3 * tri_bytes + lbvh_scratch_bytes(d.ntri) : 0) + Arena::aligned((size_t)ninst * 12) + 256;
+    scratch.size = (tree ? Arena::aligned((size_t)d.ntri * 48) + lbvh_scratch_bytes(d.ntri) : 0) + Arena::aligned((size_t)ninst * 12) + 256;
     int rc = INV_OK;
     hipError_t e = hipSuccess;
     auto bail = [&](hipError_t err, const char* what) {
@@ -439,18 +439,20 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         d.triB = keep.take<float>((size_t)d.ntri * 16);
         d.triC = keep.take<float>((size_t)d.ntri * 16);
         // with a tree the assembled triangles are scratch: the build stores them again in Morton order
-        float* A0 = tree ? scratch.take<float>((size_t)d.ntri * 16) : d.triA;
-        float* B0 = tree ? scratch.take<float>((size_t)d.ntri * 16) : d.triB;
-        float* C0 = tree ? scratch.take<float>((size_t)d.ntri * 16) : d.triC;
+        // (as 48-byte records: the gather into Morton order then pulls one or two cache lines per triangle, not three)
+        float* records = tree ? scratch.take<float>((size_t)d.ntri * 48) : nullptr;
+        float* A0 = tree ? records : d.triA;
+        float* B0 = tree ? records + 4 : d.triB;
+        float* C0 = tree ? records + 8 : d.triC;
         float* d_tr = nullptr;
         if (translations_xyz) {
             d_tr = scratch.take<float>((size_t)ninst * 12);
             if ((e = hipMemcpyAsync(d_tr, translations_xyz, (size_t)ninst * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
                 return bail(e, "hipMemcpyAsync(translations)");
         }
-        if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0)) != hipSuccess)
+        if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0, tree ? 3u : 1u)) != hipSuccess)
             return bail(e, "assemble kernel");
-        if ((e = build_lbvh(ctx->stream, d, keep, scratch, A0, B0, C0)) != hipSuccess) return bail(e, "LBVH build");
+        if ((e = build_lbvh(ctx->stream, d, keep, scratch, records)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
     *out = s;

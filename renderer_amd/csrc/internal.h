@@ -78,8 +78,10 @@ struct DeviceScene {
 
 hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, const inv_camera& cam, float* clip4,
                                 float* color3);
+// Triangle g's three 16-byte items go to A[g * stride], B[g * stride], C[g * stride] (in float4 units): stride 1
+// fills three arrays, stride 3 with B = A + 4 floats and C = A + 8 floats one array of 48-byte records.
 hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
-                           const float* translations, uint32_t ninst, float* A, float* B, float* C);
+                           const float* translations, uint32_t ninst, float* A, float* B, float* C, uint32_t stride);
 hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 // Several frames of one scene in one launch of the tile kernel (at most INV_BATCH_MAX; every frame must be
@@ -95,11 +97,11 @@ hipError_t launch_deinterleave_sparse(hipStream_t s, const FrameK& f, const uint
                                       uint64_t frame_plane_stride);
 hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
                                uint32_t* frame);
-// LBVH build over the assembled triangles A0/B0/C0: fills sc.triA/B/C (Morton order) and the tree arrays from
+// LBVH build over the assembled triangles (48-byte records: the sort's gather then pulls one or two cache lines per
+// triangle instead of three): fills sc.triA/B/C (Morton order) and the tree arrays from
 // `keep`, temporaries from `scratch` (sizes from the two functions below).  Synchronises the stream once at the end.
 size_t lbvh_keep_bytes(uint32_t ntri);
 size_t lbvh_scratch_bytes(uint32_t ntri);
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* A0, const float* B0,
-                      const float* C0);
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* records);
 
 } // namespace inv

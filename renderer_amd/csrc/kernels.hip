@@ -55,7 +55,7 @@ hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, c
 __global__ __launch_bounds__(256) void k_assemble(const float4* __restrict__ xyzw, const uint32_t* __restrict__ idx,
                                                   uint32_t base_ntri, const float* __restrict__ translations,
                                                   uint32_t ninst, float4* __restrict__ A, float4* __restrict__ B,
-                                                  float4* __restrict__ C) {
+                                                  float4* __restrict__ C, uint32_t stride) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t total = (uint64_t)base_ntri * ninst;
     if (g >= total) return;
@@ -70,18 +70,19 @@ __global__ __launch_bounds__(256) void k_assemble(const float4* __restrict__ xyz
         b.x = b.x + tx, b.y = b.y + ty, b.z = b.z + tz;
         c.x = c.x + tx, c.y = c.y + ty, c.z = c.z + tz;
     }
-    A[g] = make_float4(a.x, a.y, a.z, __uint_as_float((uint32_t)g));
-    B[g] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.z);
-    C[g] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, c.z);
+    const uint64_t at = g * stride;
+    A[at] = make_float4(a.x, a.y, a.z, __uint_as_float((uint32_t)g));
+    B[at] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.z);
+    C[at] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, c.z);
 }
 
 hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
-                           const float* translations, uint32_t ninst, float* A, float* B, float* C) {
+                           const float* translations, uint32_t ninst, float* A, float* B, float* C, uint32_t stride) {
     (void)nv;
     uint64_t total = (uint64_t)base_ntri * ninst;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4*)xyzw, idx,
-                       base_ntri, translations, ninst, (float4*)A, (float4*)B, (float4*)C);
+                       base_ntri, translations, ninst, (float4*)A, (float4*)B, (float4*)C, stride);
     return hipGetLastError();
 }
 

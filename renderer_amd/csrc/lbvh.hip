@@ -41,14 +41,14 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // partial[block][6] = lo xyz, hi xyz over the block's triangles (grid-stride)
-__global__ __launch_bounds__(256) void k_bounds_partial(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                        const float4* __restrict__ TC, uint32_t n,
+// (the assembled triangles come as 48-byte records: T[3 i], T[3 i + 1], T[3 i + 2])
+__global__ __launch_bounds__(256) void k_bounds_partial(const float4* __restrict__ T, uint32_t n,
                                                         float* __restrict__ partial) {
     __shared__ float red[4][6];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float l[3], h[3];
-        tri_box(TA[i], TB[i], TC[i], l, h);
+        tri_box(T[3 * (size_t)i], T[3 * (size_t)i + 1], T[3 * (size_t)i + 2], l, h);
 #pragma unroll
         for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], l[a]), hi[a] = fmaxf(hi[a], h[a]);
     }
@@ -98,14 +98,13 @@ __device__ __forceinline__ uint32_t grid21(float c, float lo, float ext) {
     return (uint32_t)s;
 }
 
-__global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                const float4* __restrict__ TC, uint32_t n,
+__global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, uint32_t n,
                                                 const float* __restrict__ bbox, uint64_t* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float lo[3], hi[3];
-    tri_box(TA[i], TB[i], TC[i], lo, hi);
+    tri_box(T[3 * (size_t)i], T[3 * (size_t)i + 1], T[3 * (size_t)i + 2], lo, hi);
     float ex = bbox[3] - bbox[0], ey = bbox[4] - bbox[1], ez = bbox[5] - bbox[2];
     float cx = (lo[0] + hi[0]) * 0.5f, cy = (lo[1] + hi[1]) * 0.5f, cz = (lo[2] + hi[2]) * 0.5f;
     keys[i] = (expand21(grid21(cx, bbox[0], ex)) << 2) | (expand21(grid21(cy, bbox[1], ey)) << 1) |
@@ -289,14 +288,14 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
 // ------------------------------------------------------------------------------------------
 // 4. gather the triangle records into sorted order
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_permute(const float4* __restrict__ A0, const float4* __restrict__ B0,
-                                                 const float4* __restrict__ C0, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(256) void k_permute(const float4* __restrict__ T, const uint32_t* __restrict__ order,
                                                  uint32_t n, float4* __restrict__ A1, float4* __restrict__ B1,
                                                  float4* __restrict__ C1) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s = order[i];
-    A1[i] = A0[s], B1[i] = B0[s], C1[i] = C0[s];
+    const float4* rec = T + 3 * (size_t)s;
+    A1[i] = rec[0], B1[i] = rec[1], C1[i] = rec[2];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -700,8 +699,7 @@ size_t lbvh_scratch_bytes(uint32_t n) {
     return total;
 }
 
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* A0f, const float* B0f,
-                      const float* C0f) {
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records) {
     const uint32_t n = sc.ntri;
     sc.has_bvh = false;
     if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
@@ -731,11 +729,11 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     if (!range || !sc.cut_groups) return hipErrorOutOfMemory; // the arenas were sized for something else
     float4 *A1 = (float4*)sc.triA, *B1 = (float4*)sc.triB, *C1 = (float4*)sc.triC;
 
-    const float4 *A0 = (const float4*)A0f, *B0 = (const float4*)B0f, *C0 = (const float4*)C0f;
+    const float4* T0 = (const float4*)records;
     const dim3 blk(256), grid_n((n + 255) / 256);
-    hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_blocks), blk, 0, s, A0, B0, C0, n, partial);
+    hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_blocks), blk, 0, s, T0, n, partial);
     hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, bounds_blocks, d_bbox);
-    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, A0, B0, C0, n, d_bbox, sc.morton, sc.order);
+    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, n, d_bbox, sc.morton, sc.order);
     // 63 significant key bits -> 8 passes; an even number of passes leaves the result in sc.morton / sc.order
     uint64_t* kin = sc.morton;
     uint32_t* vin = sc.order;
@@ -758,7 +756,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
-    hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, A0, B0, C0, sc.order, n, A1, B1, C1);
+    hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, T0, sc.order, n, A1, B1, C1);
     hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
