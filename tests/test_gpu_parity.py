@@ -600,10 +600,10 @@ def test_lbvh_structure_matches_the_sequential_restatement(oracle, bunny_scene, 
     _check_lbvh(oracle, bunny_scene, *bunny_mesh)
 
 
-@pytest.mark.parametrize("ntri,seed", [(2, 0), (3, 1), (257, 2), (1023, 6), (1024, 7), (1025, 8), (2048, 3), (2049, 4),
-                                       (20000, 5)])
+@pytest.mark.parametrize("ntri,seed", [(2, 0), (3, 1), (257, 2), (511, 9), (512, 10), (513, 11), (1023, 6), (1024, 7),
+                                       (1025, 8), (2048, 3), (2049, 4), (20000, 5)])
 def test_lbvh_structure_random(oracle, gpu_ctx, ntri, seed):
-    """Sizes around the sort tile (2048 keys) and the refit's chunk of leaves (1024), and duplicated triangles (equal
+    """Sizes around the sort tile (2048 keys) and the refit's chunk of leaves (512), and duplicated triangles (equal
     Morton keys, index tie-break)."""
     xyz, faces = objfmt.random_soup(ntri, seed=seed, size=0.004)
     if ntri > 100:
