@@ -154,8 +154,8 @@ __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ count
     }
 }
 
-// Large arrays: three launches.  (a) every workgroup scans its own kScanBlock counters in place and writes its
-// total, (b) one workgroup scans the totals (k_sort_scan), (c) every workgroup adds its offset.
+// Large arrays: two levels.  (a) every workgroup scans its own kScanBlock counters in place and writes its total,
+// (b) one workgroup scans the totals (k_sort_scan); the scatter adds a counter's block offset itself.
 constexpr uint32_t kScanBlock = 4096; // 1024 threads x 4 counters
 
 __global__ __launch_bounds__(1024) void k_scan_local(uint32_t* __restrict__ counts, uint32_t len,
@@ -185,40 +185,48 @@ __global__ __launch_bounds__(1024) void k_scan_local(uint32_t* __restrict__ coun
     if (threadIdx.x == 1023) totals[blockIdx.x] = part[1023];
 }
 
-__global__ __launch_bounds__(1024) void k_scan_add(uint32_t* __restrict__ counts, uint32_t len,
-                                                   const uint32_t* __restrict__ totals) {
-    const uint32_t off = totals[blockIdx.x]; // already scanned: exclusive prefix of the block totals
-    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (base + k < len) counts[base + k] += off;
-}
-
+// One pass's scatter.  Wave w of a tile takes the keys [512 w, 512 w + 512) of the tile, 64 at a time, so the rank
+// of a key among the tile's keys of the same digit (in input order: the sort is stable) is
+//     (keys of that digit in lower waves) + (in this wave's earlier rounds) + (in lower lanes of this round),
+// and the last two need no exchange between waves: per round eight ballots find the lanes with the same digit and
+// the wave's own counters in LDS carry the rounds.  One barrier, then thread d turns the four waves' counts of digit
+// d into their prefix.  `totals`: the offsets' second scan level (offset of each block of kScanBlock counters), or
+// null when the offsets are already complete.
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* __restrict__ keys_in,
                                                                const uint32_t* __restrict__ vals_in, uint32_t n,
                                                                int shift, uint32_t ntiles,
                                                                const uint32_t* __restrict__ offsets,
+                                                               const uint32_t* __restrict__ totals,
                                                                uint64_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out) {
     __shared__ uint64_t s_key[kSortTile];
     __shared__ uint32_t s_val[kSortTile];
-    __shared__ uint32_t s_wave[4][256]; // per-wave digit counts of the current round
-    __shared__ uint32_t s_run[256];     // digit counts of earlier rounds, later the tile-local digit start
+    __shared__ uint32_t s_wave[4][256]; // per wave: keys of each digit so far, later the count in lower waves
+    __shared__ uint32_t s_run[256];     // the tile's keys of each digit, later the tile-local digit start
     __shared__ uint32_t s_goff[256];    // global start of (digit, this tile)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t base = blockIdx.x * kSortTile;
+    // Workgroups go to the eight XCDs in turn, each with an L2 of its own.  Neighbouring tiles write neighbouring
+    // short runs (a tile has eight keys per digit on average): handled by the same XCD one after the other, the runs
+    // meet in one L2 and leave it as whole lines.  So XCD x takes the x-th eighth of the tiles.
+    const uint32_t per_xcd = (ntiles + 7u) >> 3;
+    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return; // block-uniform
+    const uint32_t base = tile * kSortTile;
     const uint32_t tile_n = min((uint32_t)kSortTile, n - base);
-    s_run[tid] = 0;
-    s_goff[tid] = offsets[tid * ntiles + blockIdx.x];
+    {
+        const uint32_t at = tid * ntiles + tile;
+        s_goff[tid] = offsets[at] + (totals ? totals[at / kScanBlock] : 0u);
+    }
 #pragma unroll
     for (int w = 0; w < 4; w++) s_wave[w][tid] = 0;
     __syncthreads();
 
     uint64_t key[kSortItems];
     uint32_t val[kSortItems], rank[kSortItems];
+    uint32_t* mine = s_wave[wave];
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {
-        const uint32_t j = r * kSortThreads + tid;
+        const uint32_t j = wave * (kSortItems * 64u) + r * 64u + lane;
         const bool valid = j < tile_n;
         key[r] = valid ? keys_in[base + j] : ~0ull;
         val[r] = valid ? vals_in[base + j] : 0u;
@@ -232,17 +240,18 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
             same &= bit ? bal : ~bal;
         }
         const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        if (valid && before == 0) s_wave[wave][digit] = (uint32_t)__popcll(same);
-        __syncthreads();
-        uint32_t r0 = s_run[digit] + before;
-        for (uint32_t w = 0; w < wave; w++) r0 += s_wave[w][digit];
-        rank[r] = r0;
-        __syncthreads();
-        // thread d folds digit d's round total into the running count and clears the round
-        s_run[tid] += s_wave[0][tid] + s_wave[1][tid] + s_wave[2][tid] + s_wave[3][tid];
-        s_wave[0][tid] = 0, s_wave[1][tid] = 0, s_wave[2][tid] = 0, s_wave[3][tid] = 0;
-        __syncthreads();
+        // a wave's LDS accesses execute in program order: every lane reads the count, then one lane per digit adds
+        const uint32_t earlier = mine[digit];
+        rank[r] = earlier + before;
+        if (valid && before == 0) mine[digit] = earlier + (uint32_t)__popcll(same);
     }
+    __syncthreads();
+    {
+        const uint32_t c0 = s_wave[0][tid], c1 = s_wave[1][tid], c2 = s_wave[2][tid], c3 = s_wave[3][tid];
+        s_wave[0][tid] = 0, s_wave[1][tid] = c0, s_wave[2][tid] = c0 + c1, s_wave[3][tid] = c0 + c1 + c2;
+        s_run[tid] = c0 + c1 + c2 + c3;
+    }
+    __syncthreads();
     // exclusive scan of the tile's digit counts -> tile-local digit start (s_run becomes the start)
     {
         uint32_t c = s_run[tid];
@@ -263,10 +272,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
     // stage into LDS in digit order, then write runs out with consecutive lanes on consecutive addresses
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {
-        const uint32_t j = r * kSortThreads + tid;
+        const uint32_t j = wave * (kSortItems * 64u) + r * 64u + lane;
         if (j < tile_n) {
             const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
-            const uint32_t p = s_run[digit] + rank[r];
+            const uint32_t p = s_run[digit] + mine[digit] + rank[r];
             s_key[p] = key[r];
             s_val[p] = val[r];
         }
@@ -754,10 +763,9 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
             const uint32_t nb = (ncount + kScanBlock - 1) / kScanBlock;
             hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(1024), 0, s, counts, ncount, scan_totals);
             hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, scan_totals, nb);
-            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, counts, ncount, scan_totals);
         }
-        hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(kSortThreads), 0, s, kin, vin, n, shift, ntiles, counts,
-                           kout, vout);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(((ntiles + 7u) >> 3) * 8u), dim3(kSortThreads), 0, s, kin, vin, n, shift, ntiles, counts,
+                           (const uint32_t*)(ncount <= 16384u ? nullptr : scan_totals), kout, vout);
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
