@@ -29,6 +29,14 @@ __device__ __forceinline__ void tri_box(const float4& A, const float4& B, const 
     hi[0] = fmaxf(A.x, fmaxf(bx, cx)), hi[1] = fmaxf(A.y, fmaxf(by, cy)), hi[2] = fmaxf(A.z, fmaxf(bz, cz));
 }
 
+// Workgroups go to the eight XCDs in turn, each with an L2 of its own.  Where neighbouring blocks of work touch
+// neighbouring memory, XCD x takes the x-th eighth of the blocks instead of every eighth block: launch
+// xcd_grid(nblocks) workgroups and leave if xcd_block() is not below nblocks.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks) {
+    return (blockIdx.x & 7u) * ((nblocks + 7u) >> 3) + (blockIdx.x >> 3);
+}
+static inline uint32_t xcd_grid(uint32_t nblocks) { return ((nblocks + 7u) >> 3) * 8u; }
+
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
@@ -205,11 +213,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
     __shared__ uint32_t s_run[256];     // the tile's keys of each digit, later the tile-local digit start
     __shared__ uint32_t s_goff[256];    // global start of (digit, this tile)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // Workgroups go to the eight XCDs in turn, each with an L2 of its own.  Neighbouring tiles write neighbouring
-    // short runs (a tile has eight keys per digit on average): handled by the same XCD one after the other, the runs
-    // meet in one L2 and leave it as whole lines.  So XCD x takes the x-th eighth of the tiles.
-    const uint32_t per_xcd = (ntiles + 7u) >> 3;
-    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    // Neighbouring tiles write neighbouring short runs (a tile has eight keys per digit on average): handled by the
+    // same XCD one after the other, the runs meet in one L2 and leave it as whole lines.
+    const uint32_t tile = xcd_block(ntiles);
     if (tile >= ntiles) return; // block-uniform
     const uint32_t base = tile * kSortTile;
     const uint32_t tile_n = min((uint32_t)kSortTile, n - base);
@@ -300,7 +306,8 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
 __global__ __launch_bounds__(256) void k_permute(const float4* __restrict__ T, const uint32_t* __restrict__ order,
                                                  uint32_t n, float4* __restrict__ A1, float4* __restrict__ B1,
                                                  float4* __restrict__ C1) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (neighbours in Morton order are neighbours in space and often in the input: one L2 for a stretch of them)
+    uint32_t i = xcd_block((n + 255u) / 256u) * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t s = order[i];
     const float4* rec = T + 3 * (size_t)s;
@@ -321,7 +328,8 @@ __device__ __forceinline__ int delta(const uint64_t* __restrict__ m, uint32_t n,
 __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, uint32_t n,
                                                 uint32_t* __restrict__ child, uint32_t* __restrict__ parent,
                                                 uint32_t* __restrict__ leaf_parent, uint2* __restrict__ range) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (a node's searches probe keys around its own: one L2 for a stretch of nodes)
+    int64_t i = (int64_t)xcd_block((n - 1 + 255u) / 256u) * 256 + threadIdx.x;
     if (i >= (int64_t)n - 1) return;
     if (i == 0) parent[0] = 0xFFFFFFFFu;
     int d = (delta(m, n, i, i + 1) - delta(m, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -764,13 +772,13 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
             hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(1024), 0, s, counts, ncount, scan_totals);
             hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, scan_totals, nb);
         }
-        hipLaunchKernelGGL(k_sort_scatter, dim3(((ntiles + 7u) >> 3) * 8u), dim3(kSortThreads), 0, s, kin, vin, n, shift, ntiles, counts,
+        hipLaunchKernelGGL(k_sort_scatter, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, vin, n, shift, ntiles, counts,
                            (const uint32_t*)(ncount <= 16384u ? nullptr : scan_totals), kout, vout);
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
-    hipLaunchKernelGGL(k_permute, grid_n, blk, 0, s, T0, sc.order, n, A1, B1, C1);
-    hipLaunchKernelGGL(k_karras, dim3((n - 1 + 255) / 256), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
+    hipLaunchKernelGGL(k_permute, dim3(xcd_grid((n + 255) / 256)), blk, 0, s, T0, sc.order, n, A1, B1, C1);
+    hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
     uint32_t* finished_in_chunks = ready_count + kMaxLevels + 1;
