@@ -127,16 +127,19 @@ __global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, ui
 __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
                                                             uint32_t ntiles, uint32_t* __restrict__ counts) {
     __shared__ uint32_t hist[256];
+    // (tile t writes counter t of each of the 256 digit rows: neighbouring tiles on one XCD fill whole lines)
+    const uint32_t tile = xcd_block(ntiles);
+    if (tile >= ntiles) return; // block-uniform
     hist[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t base = blockIdx.x * kSortTile;
+    uint32_t base = tile * kSortTile;
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {
         uint32_t i = base + r * kSortThreads + threadIdx.x;
         if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    counts[threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+    counts[threadIdx.x * ntiles + tile] = hist[threadIdx.x];
 }
 
 // Exclusive scan of `len` counters.  Small arrays: one workgroup of 1024 threads, a chunk per thread.
@@ -763,7 +766,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     uint32_t* vout = vals_alt;
     for (int pass = 0; pass < 8; pass++) {
         const int shift = 8 * pass;
-        hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
+        hipLaunchKernelGGL(k_sort_hist, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
         const uint32_t ncount = ntiles * 256u;
         if (ncount <= 16384u) {
             hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, counts, ncount);
