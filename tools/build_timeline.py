@@ -3,11 +3,13 @@
     python tools/build_timeline.py gpurun_out/c4prof/vm/NNN_kernel_trace.csv
 """
 import csv
+import re
 import sys
 
 
 def short(name):
-    return name.split("(")[0].split("::")[-1].replace("void ", "") or name[:40]
+    m = re.search(r"\b(k_\w+)", name)  # this library's kernels; others (runtime copies and fills) by their first word
+    return m.group(1) if m else re.split(r"[(<]", name.replace("void ", ""))[0].split("::")[-1] or name[:40]
 
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -18,7 +20,7 @@ t0 = int(rows[s]["Start_Timestamp"])
 groups = {}
 for r in rows[s:]:
     n = short(r["Kernel_Name"])
-    if "k_render" in n:
+    if n.startswith("k_render"):
         break
     a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if "-v" in sys.argv:
@@ -27,6 +29,6 @@ for r in rows[s:]:
     g[0] += 1
     g[1] += (b - a) / 1e3
     end = b
-print("build on the GPU: %.1f us from the first kernel's start to the last kernel's end" % ((end - t0) / 1e3))
+print("last scene build of the run, on the GPU: %.1f us from the first kernel's start to the last kernel's end" % ((end - t0) / 1e3))
 for n, (c, us) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
     print("%-28s %3d launches %8.1f us" % (n, c, us))

@@ -24,7 +24,7 @@ def main():
         "phase_timing_3_in_flight.txt": "tile_phase_timing_3_in_flight.txt", "host_loop.txt": "host_loop.txt",
         "tile_stats.txt": "tile_stats.txt", "block_stats.txt": "block_stats.txt",
         "phase_timing_blocks.txt": "block_phase_timing.txt", "pmc_phases.txt": "tile_instruction_mix.txt", "config4.txt": "config4.txt",
-        "pmc_cache.txt": "l2_valu_counters.txt", "pmc_ao.txt": "ao_instruction_mix.txt",
+        "pmc_cache.txt": "l2_valu_counters.txt", "build_timeline.txt": "lbvh_build_timeline.txt", "pmc_ao.txt": "ao_instruction_mix.txt",
     }
     for s, d in names.items():
         p = os.path.join(src, s)
