@@ -38,6 +38,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+import common  # noqa: E402
 import objfmt  # noqa: E402
 import renderer_amd as R  # noqa: E402
 from renderer_amd import dist as RD  # noqa: E402
@@ -61,6 +62,9 @@ WORKLOADS = {
     # the model turning at 90 degrees per second, one frame per 1/60 s: a stream of different frames from one scene
     # build (one GPU only)
     "bunny_1080p_turntable": dict(width=1920, height=1080, spp=1, flags=R.LAMBERT | R.INVERT, turntable=True),
+    # 32 x 32 translated copies of the bunny flattened into one LBVH (5 087 232 triangles), seen from far enough to
+    # show them all: stresses the build and the scene's HBM traffic; config.build_ms is the scene build
+    "bunny_x1024_1080p": dict(width=1920, height=1080, spp=1, flags=R.LAMBERT | R.INVERT, instances_side=32),
     # the headline extent in parity mode (what the reference's shaders draw: no Lambert, no invert)
     "bunny_1080p_parity": dict(width=1920, height=1080, spp=1, flags=0),
 }
@@ -91,6 +95,8 @@ def cpu_baseline(wl, camera, budget_s=8.0):
     from oracle import oracle as O
 
     xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
+    if "instances_side" in wl:
+        xyzw, idx = common.flatten_instances(xyzw, idx, common.grid_translations(wl["instances_side"]))
     w, h = wl["width"], wl["height"]
     cam = O.Camera.from_buffer_copy(bytes(camera))  # the same 204 bytes the GPU drew with
     prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"], ao_rays=wl.get("ao_rays", 0))
@@ -170,9 +176,20 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = R.Context(local_rank, stream=stream.cuda_stream)
-    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))  # every rank holds the whole scene
+    mesh = R.Mesh.load_obj(objfmt.bunny_obj_path())
+    side = wl.get("instances_side", 1)
+    translations = common.grid_translations(side) if side > 1 else None
+    build_ms = []
+    for _ in range(3):  # every rank holds the whole scene; the first build also pays for the allocations
+        t_build = time.perf_counter()
+        scene = R.Scene(ctx, mesh, translations=translations)
+        build_ms.append((time.perf_counter() - t_build) * 1e3)
+        if len(build_ms) < 3:
+            scene.close()
     ntri, nnodes, scene_bytes = scene.counts()
     cam = R.camera_reference(w, h)
+    if side > 1:  # pulled back and raised until the whole grid is in view
+        cam = common.pulled_back_camera(cam, 0.27 * side)
     if "view_translation" in wl:  # the reference camera moved: same roll and lens, another eye position
         cam.view[12], cam.view[13], cam.view[14] = wl["view_translation"]
     turntable = bool(wl.get("turntable"))
@@ -184,7 +201,7 @@ def main():
     gathered = frame = sc = None
     fif = args.frames_in_flight if world == 1 else 1  # the composite of several ranks runs on the context's stream
     # frames per submission: occlusion rays and many samples per pixel are drawn frame by frame anyway
-    fpl = args.frames_per_launch if world == 1 and not ao_rays and spp < 4 else 1
+    fpl = args.frames_per_launch if world == 1 and not ao_rays and spp < 4 and side == 1 else 1
     slots_used = fif > 1 or fpl > 1  # else: plain inv_render on the context's stream
     cb = None
     grouped = sparse and args.composite_frames > 1
@@ -432,7 +449,9 @@ def main():
                        "hit_pixel_mrays_per_s": (hit_pixels * spp + ao_rays * hit_pixels) * nframes / elapsed / 1e6,
                        "rays_per_frame": rays_per_frame, "frames_per_step": args.frames_per_step,
                        "us_per_frame": elapsed / nframes * 1e6, "flags": int(flags),
-                       "triangles": ntri, "lbvh_nodes": nnodes, "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
+                       "triangles": ntri, "lbvh_nodes": nnodes, "instances": side * side,
+                       # host wall of the scene build (upload, assembly, LBVH): first (with allocations) and last of three
+                       "build_ms": [build_ms[0], build_ms[-1]], "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0%s" % (
                                            args.composite, world, ", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
                                        if world > 1 else "1 GPU")},

@@ -20,7 +20,7 @@ def main():
     src, dst = os.path.join(ROOT, "gpurun_out", a.tag), os.path.join(ROOT, "profiles")
     names = {
         "bench_default.json": "bench_bunny_1080p.json", "bench_4k_16spp.json": "bench_bunny_4k_16spp.json",
-        "bench_ao64.json": "bench_bunny_1080p_ao64.json", "phase_timing.txt": "tile_phase_timing.txt",
+        "bench_ao64.json": "bench_bunny_1080p_ao64.json", "bench_x1024.json": "bench_bunny_x1024_1080p.json", "phase_timing.txt": "tile_phase_timing.txt",
         "phase_timing_3_in_flight.txt": "tile_phase_timing_3_in_flight.txt", "host_loop.txt": "host_loop.txt",
         "tile_stats.txt": "tile_stats.txt", "block_stats.txt": "block_stats.txt",
         "phase_timing_blocks.txt": "block_phase_timing.txt", "pmc_phases.txt": "tile_instruction_mix.txt", "config4.txt": "config4.txt",

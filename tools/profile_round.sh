@@ -12,6 +12,7 @@ B="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 60 --warmup 6
 timeout -k 10 200 python3 bench.py > "$O/bench_default.json"
 timeout -k 10 200 python3 bench.py --workload bunny_4k_16spp > "$O/bench_4k_16spp.json"
 timeout -k 10 200 python3 bench.py --workload bunny_1080p_ao64 > "$O/bench_ao64.json"
+timeout -k 10 250 python3 bench.py --workload bunny_x1024_1080p --steps 5 --warmup 1 > "$O/bench_x1024.json"
 (cd /tmp && timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $B > /dev/null 2>&1)
 (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- $B > /dev/null 2>&1)
 (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- $B > /dev/null 2>&1)
