@@ -1015,12 +1015,10 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
     Hit first = miss_hit();
     const Ray ray0 = make_ray(f, px, py, 0.5f, 0.5f);
     for (uint32_t s = 0; s < f.spp; s++) {
-        Ray ray = ray0;
-        if (s) {
-            float sx, sy;
-            sample_offset(pix, s, f.seed, sx, sy);
-            ray = make_ray(f, px, py, sx, sy);
-        }
+        // (sample 0 is the pixel centre; a ray copied from ray0 under a branch ends up in scratch memory)
+        float sx = 0.5f, sy = 0.5f;
+        if (s) sample_offset(pix, s, f.seed, sx, sy);
+        const Ray ray = make_ray(f, px, py, sx, sy);
         Hit best = miss_hit();
 #pragma unroll
         for (int c = 0; c < kBlockCap / 64; c++) {

@@ -1,7 +1,7 @@
 """Per-workgroup statistics of the tile kernel: list sizes and in-kernel cycle stamps per phase, for its 8x8 pixel
 tiles (what a single draw uses) or its 16x16 pixel blocks (--blocks: what inv_render_batch uses).
 
-    python tools/tile_stats.py [--width 1920 --height 1080] [--blocks]
+    python tools/tile_stats.py [--width 1920 --height 1080] [--blocks] [--instances-side 32]
 
 Uses the diagnostic switches in the high bits of inv_params.flags (images are not produced).
 """
@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+import common  # noqa: E402
 import objfmt  # noqa: E402
 import renderer_amd as R  # noqa: E402
 
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--blocks", action="store_true")
+    ap.add_argument("--instances-side", type=int, default=1, help="a grid of this many by this many copies, seen from afar")
     a = ap.parse_args()
     E = 16 if a.blocks else 8            # edge of a workgroup's pixel square
     mode = R.BLOCKS if a.blocks else 0
@@ -35,14 +37,19 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = R.Context(0, stream=stream.cuda_stream)
-    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))
+    side = a.instances_side
+    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()),
+                    translations=common.grid_translations(side) if side > 1 else None)
     cam = R.camera_reference(w, h)
+    if side > 1:
+        cam = common.pulled_back_camera(cam, 0.27 * side)
     _, d, p = scene.render(cam, R.make_params(w, h, flags=SKIP_AFTER2 | COUNTS | mode))
     nr, nrec = d.view(np.uint32)[::E, ::E], p[::E, ::E]
     m = (nr < 100000) & (nrec < 100000)
     print(("blocks" if a.blocks else "tiles") + " traced %d; ranges mean %.1f max %d; records mean %.1f max %d" %
           (m.sum(), nr[m].mean(), nr[m].max(), nrec[m].mean(), nrec[m].max()))
-    print("records histogram [0,1,8,16,32,64,128,256]:", np.histogram(nrec[m], bins=[0, 1, 8, 16, 32, 64, 128, 257])[0])
+    print("records histogram [0,1,8,16,32,64,128,256,...]:", np.histogram(nrec[m], bins=[0, 1, 8, 16, 32, 64, 128, 257, 1 << 30])[0])
+    print("ranges histogram [0,1,8,16,32,64,128,256,...]:", np.histogram(nr[m], bins=[0, 1, 8, 16, 32, 64, 128, 257, 1 << 30])[0])
     # stamps of the last of several launches enqueued back to back, as in a stream of frames (a launch on an idle
     # device starts its workgroups over a few microseconds, XCD after XCD)
     buf = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
@@ -75,7 +82,7 @@ def main():
     print("end   (us) percentiles 0..100:   ", " ".join("%.2f" % v for v in np.percentile(end, range(0, 101, 10))))
     i = int(np.argmax(t1 + t2 + t3))
     print("slowest block: %d records, phases %d / %d / %d cycles" % (n[i], t1[i], t2[i], t3[i]))
-    for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 256)):
+    for lo, hi in ((0, 1), (1, 8), (8, 16), (16, 32), (32, 256), (256, 1 << 30)):
         k = (n >= lo) & (n < hi)
         if k.any():
             print("records [%3d,%3d): %4d blocks, phases %6.0f / %6.0f / %6.0f cycles" %
