@@ -17,10 +17,11 @@ struct FrameK {
     float pad;                // guard pad: 2^-16 * max(|origin|, |scene coordinates|)
     float lx, ly, lz;         // unit direction towards the light in object space (Lambert); 0 if undefined
     float wf, hf;
+    float rwf, rhf;           // 1.0f / wf, 1.0f / hf, correctly rounded (host division): see div_by
     float mv[12];             // rows 0..2 of view*model (object -> view space), 4 floats each
+    float inv_p00, inv_p11;   // 1.0f / P00, 1.0f / P11, correctly rounded (div_by; also used by the culling)
     // approximate helpers for conservative culling only (never used for a pixel's value)
     float inv_w2, inv_h2;     // 2/width, 2/height
-    float inv_p00, inv_p11;   // 1/P00, 1/P11
     uint32_t rx0, ry0, rx1, ry1; // pixel rectangle that can contain hits (projected scene bounds); rest is clear
     uint32_t w, h;
     uint32_t spp, flags, seed;

@@ -114,6 +114,7 @@ int fill_layout(const inv_params& p, FrameK* f) {
     if ((uint64_t)p.width * p.height > 0x7FFFFFFFull) return fail(INV_ERR_ARG, "params: more than 2^31 pixels");
     f->w = p.width, f->h = p.height;
     f->wf = (float)p.width, f->hf = (float)p.height;
+    f->rwf = 1.0f / f->wf, f->rhf = 1.0f / f->hf;
     f->spp = p.spp ? p.spp : 1u;
     f->flags = p.flags;
     f->seed = p.seed;

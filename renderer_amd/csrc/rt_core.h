@@ -53,13 +53,28 @@ __device__ __forceinline__ void sample_offset(uint32_t pixel, uint32_t sample, u
 
 // Framebuffer position -> NDC (viewport (0,0,w,h), src/invert.cpp:784-791) -> view-space
 // direction (x_ndc/P00, y_ndc/P11, -1) -> object space.
+// a / b, bit for bit, for a divisor b whose reciprocal rb = 1.0f / b the host has computed (one correctly rounded
+// division per frame instead of eleven instructions per quotient).  q0 = a * rb is within 1.5 ulp of a / b; the
+// residual e = a - b * q is exact in a fused multiply-add, so q1 = q0 + e * rb is off by a rounding and 2^-47 of the
+// quotient: less than one ulp; and from an approximation that close and a correctly rounded reciprocal the same
+// step once more rounds the exact quotient (Markstein, "Computation of elementary functions on the IBM RISC
+// System/6000 processor", 1990, theorem on the final correction).  No intermediate over- or underflows for the
+// operands a ray has (pixel coordinates over extents, normalised coordinates over projection terms of ordinary size).
+__device__ __forceinline__ float div_by(float a, float b, float rb) {
+    float q = a * rb;
+    float e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, rb, q);
+    e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, rb, q);
+}
+
 __device__ __forceinline__ Ray make_ray(const FrameK& f, uint32_t px, uint32_t py, float sx, float sy) {
     float fx = (float)px + sx;
     float fy = (float)py + sy;
-    float xn = (2.0f * fx) / f.wf - 1.0f;
-    float yn = (2.0f * fy) / f.hf - 1.0f;
-    float dxv = xn / f.p00;
-    float dyv = yn / f.p11;
+    float xn = div_by(2.0f * fx, f.wf, f.rwf) - 1.0f;
+    float yn = div_by(2.0f * fy, f.hf, f.rhf) - 1.0f;
+    float dxv = div_by(xn, f.p00, f.inv_p00);
+    float dyv = div_by(yn, f.p11, f.inv_p11);
     Ray r;
     r.ox = f.ox, r.oy = f.oy, r.oz = f.oz;
     r.dx = (f.d0x * dxv + f.d1x * dyv) - f.d2x;

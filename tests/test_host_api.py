@@ -246,3 +246,22 @@ def test_image_writers(tmp_path):
     with pytest.raises(R.InvertError) as e:
         api.write_ppm(str(tmp_path / "nodir" / "x.ppm"), color)
     assert e.value.code == api.ERR_IO
+
+
+def test_division_by_frame_constants_is_exact(tmp_path):
+    """make_ray divides by the extent and by the projection terms with multiply-adds on a host-rounded reciprocal
+    (div_by, rt_core.h); tools/micro/div_check.c holds the same statements and compares them with IEEE division for
+    every float32 numerator of a range: here a slice of each range a ray uses, the whole ranges in the tool's header."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "micro", "div_check.c")
+    exe = str(tmp_path / "div_check")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", "-o", exe, src, "-lm"])
+    # pixel coordinates over extents; normalised coordinates over projection terms (reference camera: 45 degrees)
+    for lo, hi, divisors in (("1", "64", ["1920", "1080", "3840", "2160", "512", "333", "46340"]),
+                             ("0.25", "1", ["2.41421342", "1.35799515", "1.81066012", "0.0087268678", "114591.56"])):
+        p = subprocess.run([exe, lo, hi] + divisors, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert p.stdout.count("0 quotients differ") == len(divisors)
