@@ -184,7 +184,8 @@ int inv_frame_stream(inv_ctx* ctx, uint32_t slot, void** hip_stream);
  * attachments (LBVH traversal, no occlusion rays; shards of several ranks included) share launches, up to eight frames each, so that the
  * dispatch gap and the wait for a frame's slowest tiles are paid once per launch instead of once per frame;
  * a frame that cannot share (occlusion rays, host attachments, four or more samples per pixel, triangles far smaller
- * than a pixel, another traversal) is drawn on its own between the shared launches.  `slot` is a frame slot (see inv_render_in_flight) or INV_CONTEXT_STREAM
+ * than a pixel, another traversal) is drawn on its own between the shared launches, and so is a frame that would be
+ * alone in its launch (a draw on its own picks the kernel variant that finishes one frame soonest).  `slot` is a frame slot (see inv_render_in_flight) or INV_CONTEXT_STREAM
  * for the context's own stream. */
 #define INV_CONTEXT_STREAM 0xFFFFFFFFu
 int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const inv_camera* cams, const inv_params* params,

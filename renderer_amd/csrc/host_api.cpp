@@ -676,10 +676,13 @@ int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const in
     // Frames that can share a launch are collected (up to INV_BATCH_MAX); a frame that cannot (occlusion rays, host
     // attachments, another traversal, a variant of the tile kernel other than the blocks) is drawn on its own after
     // the launch of those collected before it.  Everything runs on one stream, and the attachments do not overlap.
-    uint32_t pending = 0;
+    // (A frame left alone is drawn as a single draw: that picks the variant that finishes one frame soonest.)
+    uint32_t pending = 0, last = 0; // frames collected; index of the latest of them
     const auto flush = [&]() -> int {
-        if (pending) HIP_TRY(launch_render_batch(stream, fk, dev, pending, scene->d));
+        const uint32_t n = pending;
         pending = 0;
+        if (n == 1) return render_on(scene, stream, *fs, &cams[last], &params[last], &outs[last]);
+        if (n) HIP_TRY(launch_render_batch(stream, fk, dev, n, scene->d));
         return INV_OK;
     };
     for (uint32_t i = 0; i < nframes; i++) {
@@ -688,7 +691,7 @@ int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const in
         if (rc != INV_OK) return rc;
         const Outputs o = {(uint8_t*)outs[i].color, (float*)outs[i].depth, (uint32_t*)outs[i].primid};
         if (outs[i].on_device && params[i].ao_rays == 0 && tile_batchable(f, scene->d, o)) {
-            dev[pending++] = o;
+            dev[pending++] = o, last = i;
             if (pending == INV_BATCH_MAX && (rc = flush()) != INV_OK) return rc;
         } else {
             if ((rc = flush()) != INV_OK) return rc;

@@ -1219,6 +1219,11 @@ __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, u
     }
 }
 
+constexpr uint32_t kXcdRun = 16; // consecutive tiles one XCD takes (see k_render_tile)
+__host__ __device__ inline uint32_t xcd_run_grid(uint32_t ntiles) { // tile workgroups launched: whole runs for all XCDs
+    return (ntiles + 8u * kXcdRun - 1u) / (8u * kXcdRun) * (8u * kXcdRun);
+}
+
 // Grid = [blocks of the hit rectangle] ++ [fill blocks]; workgroups of four waves.
 template <int MODE>
 __global__ __launch_bounds__(256, MODE == kBatched ? 1 : (MODE == kTiles ? 5 : 4)) void k_render_tile(FrameK f, TilePlan pl,
@@ -1228,10 +1233,24 @@ __global__ __launch_bounds__(256, MODE == kBatched ? 1 : (MODE == kTiles ? 5 : 4
                                                          const float4* __restrict__ cut_groups, uint32_t ncut,
                                                          AoK ao, Outputs out) {
     __shared__ typename TraceLds<MODE>::type S;
-    if (blockIdx.x < pl.ntiles)
-        tile_block<MODE>(f, pl, blockIdx.x, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
-    else
-        fill_part(f, pl, blockIdx.x - pl.ntiles, out);
+    // Workgroups go to the eight XCDs in turn, each with an L2 of its own.  Neighbouring tiles walk the same
+    // subtrees and read the same triangles, so an XCD takes runs of kXcdRun consecutive tiles instead of every eighth
+    // tile: what a tile has pulled into its L2 is there for its neighbours (the scene of a single bunny fits every L2
+    // whole; a scene of millions of triangles does not).  Runs, not an eighth of the rectangle each: the tiles' work
+    // is uneven (the bunny's body against its ears), and eight bands would leave the XCDs unevenly loaded.  Only the
+    // variant for dense scenes does this: with a few hundred tiles per frame even runs load the XCDs unevenly (two
+    // overlapping draws of the bunny took 10.0 instead of 6.3 us per frame), and such scenes gain nothing from it.
+    const uint32_t tile_grid = MODE == kBatched ? xcd_run_grid(pl.ntiles) : pl.ntiles;
+    if (blockIdx.x < tile_grid) {
+        uint32_t t = blockIdx.x;
+        if (MODE == kBatched) {
+            const uint32_t k = blockIdx.x >> 3; // position in this XCD's sequence
+            t = ((k / kXcdRun) * 8u + (blockIdx.x & 7u)) * kXcdRun + k % kXcdRun;
+        }
+        if (t < pl.ntiles) tile_block<MODE>(f, pl, t, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+    } else {
+        fill_part(f, pl, blockIdx.x - tile_grid, out);
+    }
 }
 
 // Several frames in one launch (different cameras, extents and attachments, one scene).
@@ -1482,7 +1501,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     const TilePlan pl = plan_tile_frame(f, sc, out, false, &mode);
     if (pl.ntiles + pl.fill_blocks == 0) return hipSuccess;
 #define INV_LAUNCH_TILE(MODE)                                                                                        \
-    hipLaunchKernelGGL((k_render_tile<MODE>), dim3(pl.ntiles + pl.fill_blocks), dim3(256), 0, s, f, pl,              \
+    hipLaunchKernelGGL((k_render_tile<MODE>), dim3((MODE == kBatched ? xcd_run_grid(pl.ntiles) : pl.ntiles) + pl.fill_blocks), dim3(256), 0, s, f, pl, \
                        (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, \
                        (const float4*)sc.cut, (const float4*)sc.cut_groups, sc.ncut, ao, out)
     if (mode == kBatched)
