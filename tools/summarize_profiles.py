@@ -32,9 +32,10 @@ def short(name):
 
 
 def pmc_avg(d, counter):
-    files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+    # the newest file only: gpurun merges results into gpurun_out/, where an earlier pass of the same name may linger
+    files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(list)
-    for f in files:
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
@@ -53,10 +54,10 @@ def main():
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(a.stats_dir, "**", "*_kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(a.stats_dir, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(out, a.tag + "_kernel_stats.csv"))
-        print("copied", stats[0])
+        shutil.copy(stats[-1], os.path.join(out, a.tag + "_kernel_stats.csv"))
+        print("copied", stats[-1])
     if a.fetch and a.write:
         fe, wr = pmc_avg(a.fetch, "FETCH_SIZE"), pmc_avg(a.write, "WRITE_SIZE")
         kernels = {}
