@@ -620,6 +620,22 @@ def test_lbvh_structure_random(oracle, gpu_ctx, ntri, seed):
     scene.close()
 
 
+def test_lbvh_structure_large_instanced_scene(oracle, gpu_ctx, bunny_mesh):
+    """12 x 12 copies (715 392 triangles: 350 sort tiles on all XCDs, 1 400 refit chunks): sorted
+    keys, order, hierarchy and every box against the sequential restatement; then the same after a smaller build has
+    used the context's scratch memory in between."""
+    xyzw, idx = bunny_mesh
+    tr = common.grid_translations(12)
+    fx, fi = common.flatten_instances(xyzw, idx, tr)
+    mesh = R.Mesh.from_arrays(xyzw, idx)
+    for _ in range(2):
+        scene = R.Scene(gpu_ctx, mesh, translations=tr)
+        _check_lbvh(oracle, scene, fx, fi)
+        scene.close()
+        R.Scene(gpu_ctx, mesh).close()
+    mesh.close()
+
+
 @pytest.mark.parametrize("ntri,size", [(700, 0.02), (6000, 0.03)])
 def test_tile_kernel_list_overflow_paths(oracle, gpu_ctx, ntri, size):
     """Dense overlapping soups at 64x64: more candidates per 8x8 tile than the record list (256) and, for the larger
