@@ -125,9 +125,18 @@ struct RaySlabs {
     float chx, chy, chz; // (origin - grow) / direction
 };
 
+// A direction component of exactly zero (the centre ray of a frame with odd width and height runs along the view
+// axis) would make the reciprocal infinite, and the folded form then computes inf - inf where the unfolded one has
+// (l - o) * inf: a not-a-number that the minimum and maximum drop on the wrong side.  For the box tests such a
+// component is taken as 2^-60 with its sign: over any ray length in a scene the ray then leaves its true line by
+// less than a rounding error, and every product stays finite with the margin-to-rounding ratio unchanged.
+__device__ __forceinline__ float slab_reciprocal(float d) {
+    return 1.0f / (fabsf(d) >= 0x1p-60f ? d : copysignf(0x1p-60f, d));
+}
+
 __device__ __forceinline__ RaySlabs make_slabs(float ox, float oy, float oz, float dx, float dy, float dz, float grow) {
     RaySlabs s;
-    s.ix = 1.0f / dx, s.iy = 1.0f / dy, s.iz = 1.0f / dz;
+    s.ix = slab_reciprocal(dx), s.iy = slab_reciprocal(dy), s.iz = slab_reciprocal(dz);
     s.clx = (ox + grow) * s.ix, s.cly = (oy + grow) * s.iy, s.clz = (oz + grow) * s.iz;
     s.chx = (ox - grow) * s.ix, s.chy = (oy - grow) * s.iy, s.chz = (oz - grow) * s.iz;
     return s;
@@ -138,7 +147,7 @@ __device__ __forceinline__ bool slab_folded(const RaySlabs& s, float lx, float l
     const float ax = __builtin_fmaf(lx, s.ix, -s.clx), bx = __builtin_fmaf(hx, s.ix, -s.chx);
     const float ay = __builtin_fmaf(ly, s.iy, -s.cly), by = __builtin_fmaf(hy, s.iy, -s.chy);
     const float az = __builtin_fmaf(lz, s.iz, -s.clz), bz = __builtin_fmaf(hz, s.iz, -s.chz);
-    // fminf/fmaxf drop NaNs (0 * inf, inf - inf), which keeps the test conservative
+    // (the reciprocals are finite, see slab_reciprocal, so nothing here is infinite or not a number)
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     tnear = t0;

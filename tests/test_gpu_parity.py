@@ -568,6 +568,28 @@ def test_8k_frame_properties(bunny_scene, gpu_ctx):
     assert float(depth.min()) > 0.90 and float(depth.max()) < 0.92  # the bunny's depth range (0.9028 .. 0.9150)
 
 
+def test_ray_along_the_view_axis(oracle, bunny_scene, bunny_mesh):
+    """Odd width and height: the centre pixel's ray has normalised coordinates (0, 0) and, with an unturned model, two
+    direction components of exactly zero.  With the eye raised so that this ray hits the model, the box tests of the
+    per-lane traversal (and of the blocks that fall back to it on so small a frame) have to cope with a direction
+    whose reciprocal is infinite.  (Found by tools/fuzz_parity.py: the pixel came out as background.)"""
+    for w, h, eye in ((81, 309, (0.043, 0.0619, -1.636)), (33, 33, (0.0, 0.11, -0.6)), (255, 129, (0.0, 0.1, -1.0))):
+        cam = R.camera_reference(w, h)
+        cam.view[12], cam.view[13], cam.view[14] = eye
+        for flags in (0, R.BLOCKS, R.LANE_TRAVERSAL, R.BRUTE_FORCE):
+            prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT | flags)
+            got = bunny_scene.render(cam, prm)
+            want = oracle.render_bvh(*bunny_mesh, oracle.Camera.from_buffer_copy(bytes(cam)), _oracle_params(oracle, prm))
+            assert want[2][h // 2, w // 2] != 0xFFFFFFFF, "the centre ray is meant to hit"
+            common.assert_frames_equal(got, want, "%dx%d flags %d" % (w, h, flags))
+    # and occlusion rays: their directions come from a table and may have zero components as well
+    cam = R.camera_reference(65, 65)
+    cam.view[13], cam.view[14] = 0.11, -0.5
+    prm = R.make_params(65, 65, ao_rays=16, flags=R.LAMBERT)
+    want = oracle.render_bvh(*bunny_mesh, oracle.Camera.from_buffer_copy(bytes(cam)), _oracle_params(oracle, prm))
+    common.assert_frames_equal(bunny_scene.render(cam, prm), want, "centre ray + occlusion")
+
+
 def test_errors(bunny_scene):
     cam = R.camera_reference(64, 64)
     with pytest.raises(R.InvertError):

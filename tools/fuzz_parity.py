@@ -1,0 +1,84 @@
+"""Random frames through the C ABI against the CPU oracle, bit for bit: extents (odd ones too), fields of view,
+eye positions, model turns, flags, kernel variants, samples per pixel and seeds that no test fixes.
+
+    python tools/fuzz_parity.py [--frames 400] [--seed 1]
+
+Exit status 1 at the first frame whose colour, depth or primitive ids differ (its parameters are printed).
+"""
+import argparse
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import objfmt  # noqa: E402
+import renderer_amd as R  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    O.build()
+    rng = np.random.default_rng(a.seed)
+    ctx = R.Context(0)
+    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))
+    xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
+    variants = (0, 0, R.BLOCKS, R.LANE_TRAVERSAL)
+    hits = 0
+    for i in range(a.frames):
+        w, h = int(rng.integers(9, 900)), int(rng.integers(9, 700))
+        cam = R.camera_turntable(w, h, float(rng.uniform(0.0, 4.0))) if rng.random() < 0.5 else R.camera_reference(w, h)
+        # a GLM-style perspective with another field of view (float32 arithmetic, as glm::perspective does it)
+        fovy = float(rng.uniform(4.0, 140.0))
+        t = np.float32(math.tan(float(np.float32(math.radians(fovy)) / np.float32(2.0))))
+        aspect = np.float32(w) / np.float32(h)
+        cam.proj[0] = float(np.float32(1.0) / (aspect * t))
+        cam.proj[5] = float(np.float32(1.0) / t)
+        # the eye somewhere in front of the model, off the axis at times
+        dist = float(rng.uniform(0.25, 3.0))
+        cam.view[12] = float(np.float32(rng.uniform(-0.05, 0.05)))
+        cam.view[13] = float(np.float32(rng.uniform(0.02, 0.2)))
+        cam.view[14] = float(-np.float32(dist))
+        flags = int(rng.choice([0, R.LAMBERT, R.INVERT, R.LAMBERT | R.INVERT, R.LAMBERT | R.INVERT | R.RGBA]))
+        variant = int(variants[int(rng.integers(0, len(variants)))])
+        spp = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 8]))
+        seed = int(rng.integers(0, 2**31))
+        prm = R.make_params(w, h, spp=spp, flags=flags | variant, seed=seed)
+        got = scene.render(cam, prm)
+        want = O.render_bvh(xyzw, idx, O.Camera.from_buffer_copy(bytes(cam)), O.make_params(w, h, spp, 0, flags, seed))
+        ok = (np.array_equal(got[2], want[2]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+              and np.array_equal(got[0], want[0]))
+        nh = int((want[2] != 0xFFFFFFFF).sum())
+        hits += nh
+        if not ok:
+            print("frame %d differs: %dx%d fovy %.3f dist %.3f view %r flags %d variant %d spp %d seed %d; "
+                  "primid %d depth %d colour %d pixels differ"
+                  % (i, w, h, fovy, dist, [cam.view[12], cam.view[13], cam.view[14]], flags, variant, spp, seed,
+                     int((got[2] != want[2]).sum()), int((got[1].view(np.uint32) != want[1].view(np.uint32)).sum()),
+                     int((got[0] != want[0]).any(axis=-1).sum())))
+            ys, xs = np.nonzero((got[2] != want[2]) | (got[1].view(np.uint32) != want[1].view(np.uint32)) | (got[0] != want[0]).any(axis=-1))
+            for y, x in list(zip(ys, xs))[:4]:
+                print("  pixel (%d, %d): primid %d / oracle %d, depth %r / %r, colour %r / %r"
+                      % (x, y, got[2][y, x], want[2][y, x], float(got[1][y, x]), float(want[1][y, x]), got[0][y, x].tolist(), want[0][y, x].tolist()))
+            for name, v in (("tiles", 0), ("blocks", R.BLOCKS), ("lanes", R.LANE_TRAVERSAL), ("brute force", R.BRUTE_FORCE)):
+                g = scene.render(cam, R.make_params(w, h, spp=spp, flags=flags | v, seed=seed))
+                same = (np.array_equal(g[2], want[2]) and np.array_equal(g[1].view(np.uint32), want[1].view(np.uint32))
+                        and np.array_equal(g[0], want[0]))
+                print("  %-12s %s" % (name, "equals the oracle" if same else "differs"))
+            print("  camera bytes:", bytes(cam).hex())
+            return 1
+        if (i + 1) % 50 == 0:
+            print("%d frames bit-exact so far (%d hit pixels)" % (i + 1, hits), flush=True)
+    print("%d random frames bit-exact against the oracle (%d hit pixels in all)" % (a.frames, hits))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
