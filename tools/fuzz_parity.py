@@ -1,5 +1,6 @@
-"""Random frames through the C ABI against the CPU oracle, bit for bit: extents (odd ones too), fields of view,
-eye positions, model turns, flags, kernel variants, samples per pixel and seeds that no test fixes.
+"""Random frames through the C ABI against the CPU oracle, bit for bit: scenes (the bunny, grids of copies, triangle
+soups), extents (odd ones too), fields of view, eye positions, model turns, flags, kernel variants, samples per pixel,
+occlusion rays and seeds that no test fixes.
 
     python tools/fuzz_parity.py [--frames 400] [--seed 1]
 
@@ -15,6 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
+import common  # noqa: E402
 import objfmt  # noqa: E402
 import renderer_amd as R  # noqa: E402
 from oracle import oracle as O  # noqa: E402
@@ -28,12 +30,36 @@ def main():
     O.build()
     rng = np.random.default_rng(a.seed)
     ctx = R.Context(0)
-    scene = R.Scene(ctx, R.Mesh.load_obj(objfmt.bunny_obj_path()))
-    xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
+    bunny_xyzw, bunny_idx = O.load_obj(objfmt.bunny_obj_path())
+    scene = None
+
+    def new_scene():
+        kind = int(rng.integers(0, 4))
+        if kind <= 1:  # the bunny
+            return "bunny", bunny_xyzw, bunny_idx, R.Scene(ctx, R.Mesh.from_arrays(bunny_xyzw, bunny_idx))
+        if kind == 2:  # a grid of copies, flattened by the library / by numpy for the oracle
+            side = int(rng.integers(2, 5))
+            tr = common.grid_translations(side)
+            fx, fi = common.flatten_instances(bunny_xyzw, bunny_idx, tr)
+            return "grid %d" % side, fx, fi, R.Scene(ctx, R.Mesh.from_arrays(bunny_xyzw, bunny_idx), translations=tr)
+        n = int(rng.integers(1, 6000))  # a soup of triangles around the place the bunny stands
+        xyz, faces = objfmt.random_soup(n, seed=int(rng.integers(0, 1 << 30)), lo=(-0.08, 0.03, -0.06), hi=(0.06, 0.19, 0.06),
+                                        size=float(rng.choice([0.003, 0.01, 0.04])))
+        xyzw = np.zeros((len(xyz), 4), np.float32)
+        xyzw[:, :3] = xyz
+        fi = faces.reshape(-1).astype(np.uint32)
+        return "soup %d" % n, xyzw, fi, R.Scene(ctx, R.Mesh.from_arrays(xyzw, fi))
+
     variants = (0, 0, R.BLOCKS, R.LANE_TRAVERSAL)
     hits = 0
     for i in range(a.frames):
-        w, h = int(rng.integers(9, 900)), int(rng.integers(9, 700))
+        if i % 40 == 0:
+            if scene is not None:
+                scene.close()
+            what, xyzw, idx, scene = new_scene()
+        ao_rays = int(rng.choice([4, 16, 64])) if rng.random() < 0.12 else 0
+        big = 300 if ao_rays else 900
+        w, h = int(rng.integers(9, big)), int(rng.integers(9, big * 7 // 9))
         cam = R.camera_turntable(w, h, float(rng.uniform(0.0, 4.0))) if rng.random() < 0.5 else R.camera_reference(w, h)
         # a GLM-style perspective with another field of view (float32 arithmetic, as glm::perspective does it)
         fovy = float(rng.uniform(4.0, 140.0))
@@ -42,25 +68,25 @@ def main():
         cam.proj[0] = float(np.float32(1.0) / (aspect * t))
         cam.proj[5] = float(np.float32(1.0) / t)
         # the eye somewhere in front of the model, off the axis at times
-        dist = float(rng.uniform(0.25, 3.0))
+        dist = float(rng.uniform(0.25, 3.0)) * (3.0 if what.startswith("grid") else 1.0)
         cam.view[12] = float(np.float32(rng.uniform(-0.05, 0.05)))
         cam.view[13] = float(np.float32(rng.uniform(0.02, 0.2)))
         cam.view[14] = float(-np.float32(dist))
         flags = int(rng.choice([0, R.LAMBERT, R.INVERT, R.LAMBERT | R.INVERT, R.LAMBERT | R.INVERT | R.RGBA]))
         variant = int(variants[int(rng.integers(0, len(variants)))])
-        spp = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 8]))
+        spp = 1 if ao_rays else int(rng.choice([1, 1, 1, 2, 3, 4, 5, 8]))  # occlusion rays go with one sample per pixel
         seed = int(rng.integers(0, 2**31))
-        prm = R.make_params(w, h, spp=spp, flags=flags | variant, seed=seed)
+        prm = R.make_params(w, h, spp=spp, ao_rays=ao_rays, flags=flags | variant, seed=seed)
         got = scene.render(cam, prm)
-        want = O.render_bvh(xyzw, idx, O.Camera.from_buffer_copy(bytes(cam)), O.make_params(w, h, spp, 0, flags, seed))
+        want = O.render_bvh(xyzw, idx, O.Camera.from_buffer_copy(bytes(cam)), O.make_params(w, h, spp, ao_rays, flags, seed))
         ok = (np.array_equal(got[2], want[2]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
               and np.array_equal(got[0], want[0]))
         nh = int((want[2] != 0xFFFFFFFF).sum())
         hits += nh
         if not ok:
-            print("frame %d differs: %dx%d fovy %.3f dist %.3f view %r flags %d variant %d spp %d seed %d; "
+            print("frame %d (%s, %d occlusion rays) differs: %dx%d fovy %.3f dist %.3f view %r flags %d variant %d spp %d seed %d; "
                   "primid %d depth %d colour %d pixels differ"
-                  % (i, w, h, fovy, dist, [cam.view[12], cam.view[13], cam.view[14]], flags, variant, spp, seed,
+                  % (i, what, ao_rays, w, h, fovy, dist, [cam.view[12], cam.view[13], cam.view[14]], flags, variant, spp, seed,
                      int((got[2] != want[2]).sum()), int((got[1].view(np.uint32) != want[1].view(np.uint32)).sum()),
                      int((got[0] != want[0]).any(axis=-1).sum())))
             ys, xs = np.nonzero((got[2] != want[2]) | (got[1].view(np.uint32) != want[1].view(np.uint32)) | (got[0] != want[0]).any(axis=-1))
@@ -68,7 +94,7 @@ def main():
                 print("  pixel (%d, %d): primid %d / oracle %d, depth %r / %r, colour %r / %r"
                       % (x, y, got[2][y, x], want[2][y, x], float(got[1][y, x]), float(want[1][y, x]), got[0][y, x].tolist(), want[0][y, x].tolist()))
             for name, v in (("tiles", 0), ("blocks", R.BLOCKS), ("lanes", R.LANE_TRAVERSAL), ("brute force", R.BRUTE_FORCE)):
-                g = scene.render(cam, R.make_params(w, h, spp=spp, flags=flags | v, seed=seed))
+                g = scene.render(cam, R.make_params(w, h, spp=spp, ao_rays=ao_rays, flags=flags | v, seed=seed))
                 same = (np.array_equal(g[2], want[2]) and np.array_equal(g[1].view(np.uint32), want[1].view(np.uint32))
                         and np.array_equal(g[0], want[0]))
                 print("  %-12s %s" % (name, "equals the oracle" if same else "differs"))
