@@ -83,6 +83,40 @@ def main():
         held.clear()
         return ok
 
+    composites = 0
+
+    def composite_equals(cam, w, h, kw, want):
+        # the frame once more as several ranks would draw it, the ranks played one after another on this GPU:
+        # dense (every tile dealt out, slots put back together on the host) or sparse (rank 0 draws into the frame, the
+        # others' tiles arrive as a gather would deliver them and inv_deinterleave_sparse copies them in)
+        nranks, tile = int(rng.integers(2, 9)), int(rng.choice([32, 64, 96, 128]))
+        if rng.random() < 0.4:
+            parts = [scene.render(cam, R.make_params(w, h, tile=tile, rank=r, nranks=nranks, **kw)) for r in range(nranks)]
+            got = [common.slots_to_frame([p[k] for p in parts], w, h, tile, nranks) for k in range(3)]
+            kind = "dense"
+        else:
+            kw = dict(kw, flags=kw["flags"] | R.SPARSE)
+            rect = scene.hit_rect(cam, w, h)
+            prm = [R.make_params(w, h, tile=tile, rank=r, nranks=nranks, **kw) for r in range(nranks)]
+            _, n, _ = R.sparse_layout(prm[1], rect)
+            frame = torch.full((3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+            gathered = torch.full((nranks, 3, max(n, 1)), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for r in range(nranks):
+                o = frame if r == 0 else gathered[r]
+                scene.render_device(cam, prm[r], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+            ctx.deinterleave_sparse(prm[0], rect, gathered.data_ptr(), 3 * max(n, 1), max(n, 1), 3, frame.data_ptr(), h * w)
+            ctx.synchronize()
+            f = frame.cpu().numpy()
+            got = [f[0].view(np.uint8).reshape(h, w, 4), f[1].view(np.float32).reshape(h, w), f[2].view(np.uint32).reshape(h, w)]
+            kind = "sparse"
+        ok = (np.array_equal(got[2], want[2]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+              and np.array_equal(got[0], want[0]))
+        if not ok:
+            print("the %s composite of %d ranks with %d-pixel tiles differs: %dx%d %r, camera bytes %s"
+                  % (kind, nranks, tile, w, h, kw, bytes(cam).hex()))
+        return ok
+
     for i in range(a.frames):
         if i % 40 == 0:
             if scene is not None:
@@ -133,6 +167,10 @@ def main():
                 print("  %-12s %s" % (name, "equals the oracle" if same else "differs"))
             print("  camera bytes:", bytes(cam).hex())
             return 1
+        if rng.random() < 0.2:
+            composites += 1
+            if not composite_equals(cam, w, h, dict(spp=spp, ao_rays=ao_rays, flags=flags | variant, seed=seed), want):
+                return 1
         if ao_rays == 0 and w * h < 400000:
             held.append((cam, prm, want))
             if len(held) == int(rng.integers(2, 10)) or len(held) >= 9:
@@ -143,7 +181,8 @@ def main():
     if not draw_held():
         return 1
     print("%d random frames bit-exact against the oracle (%d hit pixels in all); %d batches of them drawn again through "
-          "inv_render_batch, bit-exact too" % (a.frames, hits, batches))
+          "inv_render_batch and %d as the shards of several ranks put together again, bit-exact too"
+          % (a.frames, hits, batches, composites))
     return 0
 
 
