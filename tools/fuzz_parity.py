@@ -2,7 +2,7 @@
 soups), extents (odd ones too), fields of view, eye positions, model turns, flags, kernel variants, samples per pixel,
 occlusion rays and seeds that no test fixes.
 
-    python tools/fuzz_parity.py [--frames 400] [--seed 1]
+    python tools/fuzz_parity.py [--frames 400] [--seed 1] [--max-width 900]
 
 Exit status 1 at the first frame whose colour, depth or primitive ids differ (its parameters are printed).
 """
@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-width", type=int, default=900, help="widths up to this, heights up to 7/9 of it")
     a = ap.parse_args()
     O.build()
     rng = np.random.default_rng(a.seed)
@@ -125,7 +126,7 @@ def main():
                 scene.close()
             what, xyzw, idx, scene = new_scene()
         ao_rays = int(rng.choice([4, 16, 64])) if rng.random() < 0.12 else 0
-        big = 300 if ao_rays else 900
+        big = min(300, a.max_width) if ao_rays else a.max_width
         w, h = int(rng.integers(9, big)), int(rng.integers(9, big * 7 // 9))
         cam = R.camera_turntable(w, h, float(rng.uniform(0.0, 4.0))) if rng.random() < 0.5 else R.camera_reference(w, h)
         # a GLM-style perspective with another field of view (float32 arithmetic, as glm::perspective does it)
