@@ -52,7 +52,7 @@ def main():
         fi = faces.reshape(-1).astype(np.uint32)
         return "soup %d" % n, xyzw, fi, R.Scene(ctx, R.Mesh.from_arrays(xyzw, fi))
 
-    variants = (0, 0, R.BLOCKS, R.LANE_TRAVERSAL)
+    variants = (0, 0, 0, R.BLOCKS, R.BLOCKS, R.LANE_TRAVERSAL, R.BRUTE_FORCE)
     hits = 0
     held = []  # frames of the current scene waiting to be drawn once more, together, by inv_render_batch
     batches = 0
@@ -127,7 +127,7 @@ def main():
             what, xyzw, idx, scene = new_scene()
         ao_rays = int(rng.choice([4, 16, 64])) if rng.random() < 0.12 else 0
         big = min(300, a.max_width) if ao_rays else a.max_width
-        w, h = int(rng.integers(9, big)), int(rng.integers(9, big * 7 // 9))
+        w, h = int(rng.integers(1, big)), int(rng.integers(1, max(2, big * 7 // 9)))
         cam = R.camera_turntable(w, h, float(rng.uniform(0.0, 4.0))) if rng.random() < 0.5 else R.camera_reference(w, h)
         # a GLM-style perspective with another field of view (float32 arithmetic, as glm::perspective does it)
         fovy = float(rng.uniform(4.0, 140.0))
