@@ -172,7 +172,7 @@ def main():
             composites += 1
             if not composite_equals(cam, w, h, dict(spp=spp, ao_rays=ao_rays, flags=flags | variant, seed=seed), want):
                 return 1
-        if ao_rays == 0 and w * h < 400000:
+        if ao_rays == 0 and w * h < 3000000:
             held.append((cam, prm, want))
             if len(held) == int(rng.integers(2, 10)) or len(held) >= 9:
                 if not draw_held():
