@@ -83,8 +83,13 @@ typedef struct inv_outputs {
 /* Picks GPU `device` and a stream.  `hip_stream` may be an existing hipStream_t (e.g. the caller's current
  * stream) or NULL to create one.  Fails with INV_ERR_NO_DEVICE when no HIP device is present. */
 int inv_ctx_create(int device, void* hip_stream, inv_ctx** out);
+/* Waits for the context's stream and frees the context.  Scenes hold a pointer to their context: destroy every
+ * scene first (INV_ERR_ARG while one is alive; nothing is freed then). */
 int inv_ctx_destroy(inv_ctx* ctx);
 int inv_ctx_synchronize(inv_ctx* ctx);
+/* The hipStream_t the context enqueues on (the one given to inv_ctx_create, or the one it created): callers that
+ * follow a draw with work of their own (a collective, a copy) enqueue it there or order their stream after it. */
+int inv_ctx_stream(inv_ctx* ctx, void** hip_stream);
 /* A context keeps the device memory its last scene build needed only while it ran (about 120 bytes per triangle),
  * so that the next build does not allocate it again: the counterpart of the staging buffer transferData creates and
  * destroys on every call, with the TODO to keep it (src/invert.cpp:991-992, 1000-1032, 1078-1079).  This call

@@ -22,7 +22,7 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEV
 
 # every symbol include/invert.h declares
 SYMBOLS = (
-    "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize", "inv_ctx_trim",
+    "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize", "inv_ctx_trim", "inv_ctx_stream",
     "inv_mesh_load_obj", "inv_mesh_load_obj_general", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
     "inv_mesh_indices", "inv_mesh_pin", "inv_mesh_destroy",
     "inv_camera_reference", "inv_camera_turntable",
@@ -79,6 +79,7 @@ def lib():
     L.inv_ctx_destroy.argtypes = [vp]
     L.inv_ctx_synchronize.argtypes = [vp]
     L.inv_ctx_trim.argtypes = [vp]
+    L.inv_ctx_stream.argtypes = [vp, C.POINTER(vp)]
     L.inv_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_mesh_load_obj_general.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -247,6 +248,9 @@ class Context:
         _chk(lib().inv_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
         self.device = device
+        s = C.c_void_p()
+        _chk(lib().inv_ctx_stream(h, C.byref(s)))
+        self.stream = s.value or 0  # hipStream_t the context enqueues on (the one passed in, or its own)
 
     def synchronize(self):
         _chk(lib().inv_ctx_synchronize(self._h))
@@ -282,9 +286,16 @@ class Context:
                                            frame_plane_stride))
 
     def close(self):
+        """inv_ctx_destroy; raises while scenes built on this context are still open (close them first)."""
         if self._h:
-            lib().inv_ctx_destroy(self._h)
+            _chk(lib().inv_ctx_destroy(self._h))
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def tile_layout(prm: Params):
@@ -422,3 +433,9 @@ class Scene:
         if self._h:
             lib().inv_scene_destroy(self._h)
             self._h = None
+
+    def __del__(self):  # a scene keeps its context alive (self.ctx), so the context is always closed after it
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -6,6 +6,8 @@
 #include <memory>
 #include <new>
 
+#include <hip/hip_runtime.h>
+
 #include "internal.h"
 
 namespace inv {
@@ -51,6 +53,8 @@ struct inv_ctx {
     // what a scene build needs only while it runs; kept for the next build of this context (inv_ctx_trim frees it)
     void* build_scratch = nullptr;
     size_t build_scratch_bytes = 0;
+
+    uint32_t live_scenes = 0;         // scenes built on this context and not yet destroyed
 };
 
 struct inv_mesh {
@@ -111,7 +115,12 @@ void free_frame_scratch(FrameScratch& fs) {
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).
 int fill_layout(const inv_params& p, FrameK* f) {
     if (p.width == 0 || p.height == 0) return fail(INV_ERR_ARG, "params: width and height must be non-zero");
+    // Culling takes pixel coordinates through float32 with 1/16 pixel of slack: that stays far above one rounding of
+    // the normalised coordinate only while an extent is well below 2^19 pixels.
+    if (p.width > 65536u || p.height > 65536u) return fail(INV_ERR_ARG, "params: width and height are at most 65536");
     if ((uint64_t)p.width * p.height > 0x7FFFFFFFull) return fail(INV_ERR_ARG, "params: more than 2^31 pixels");
+    if (p.spp > 4096u) return fail(INV_ERR_ARG, "params: at most 4096 samples per pixel");
+    if (p.nranks > 65536u) return fail(INV_ERR_ARG, "params: at most 65536 ranks");
     f->w = p.width, f->h = p.height;
     f->wf = (float)p.width, f->hf = (float)p.height;
     f->rwf = 1.0f / f->wf, f->rhf = 1.0f / f->hf;
@@ -194,7 +203,10 @@ int inv_ctx_create(int device, void* hip_stream, inv_ctx** out) {
 
 int inv_ctx_destroy(inv_ctx* ctx) {
     if (!ctx) return INV_OK;
+    if (ctx->live_scenes)
+        return fail(INV_ERR_ARG, "inv_ctx_destroy: scenes built on this context are still alive; destroy them first");
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (uint32_t i = 0; i < INV_MAX_FRAMES_IN_FLIGHT; i++) {
         if (ctx->flight[i]) (void)hipStreamSynchronize(ctx->flight[i]), (void)hipStreamDestroy(ctx->flight[i]);
         if (ctx->flight_done[i]) (void)hipEventDestroy(ctx->flight_done[i]);
@@ -202,6 +214,12 @@ int inv_ctx_destroy(inv_ctx* ctx) {
     if (ctx->build_scratch) (void)hipFree(ctx->build_scratch);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return INV_OK;
+}
+
+int inv_ctx_stream(inv_ctx* ctx, void** hip_stream) {
+    if (!ctx || !hip_stream) return fail(INV_ERR_ARG, "inv_ctx_stream: null argument");
+    *hip_stream = (void*)ctx->stream;
     return INV_OK;
 }
 
@@ -456,6 +474,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         if ((e = build_lbvh(ctx->stream, d, keep, scratch, records)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
+    ctx->live_scenes++;
     *out = s;
     return INV_OK;
 }
@@ -485,6 +504,7 @@ int inv_scene_destroy(inv_scene* scene) {
     free_frame_scratch(scene->main);
     for (auto& fsr : scene->flight) free_frame_scratch(fsr);
     dfree(scene->vs_stage);
+    if (scene->ctx->live_scenes) scene->ctx->live_scenes--;
     delete scene;
     return INV_OK;
 }

@@ -19,6 +19,31 @@ import torch.distributed as dist
 from . import api
 
 
+def order_current_stream_after(ctx: api.Context) -> None:
+    """Make torch's current stream wait for everything enqueued on the context's stream so far.
+
+    The library draws on the context's stream; torch.distributed enqueues a collective on torch's current stream.
+    They are the same stream only if the context was created on it (Context(device, stream=...)); otherwise the
+    collective would read tiles that may not have been drawn yet.  An event recorded on the context's stream and
+    waited for by the current stream orders them on the device (no host wait; nothing to do when they coincide)."""
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream == ctx.stream:
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.ExternalStream(ctx.stream))
+    cur.wait_event(ev)
+
+
+def order_context_stream_after_current(ctx: api.Context) -> None:
+    """The other direction: what the context enqueues next (the copy of received tiles) waits for the collective."""
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream == ctx.stream:
+        return
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    torch.cuda.ExternalStream(ctx.stream).wait_event(ev)
+
+
 def shard_params(width, height, rank, world, tile=64, **kw) -> api.Params:
     """Params for this rank: it renders the tiles with tile_id % world == rank."""
     return api.make_params(width, height, tile=tile, rank=rank, nranks=world, **kw)
@@ -57,6 +82,11 @@ class SparseComposite:
         sc.render()            # every rank: enqueue the draw of its share
         sc.composite()         # every rank: the gather; rank 0 also copies the received tiles into sc.frame
         sc.frame               # rank 0: [3, h*w] int32 planes (colour, depth bits, primitive id); None elsewhere
+
+    The draw and the copy of received tiles run on the context's stream, the collective on torch's current stream.
+    With a context created on torch's current stream they are one stream; otherwise gather() orders the two streams
+    with events on the device (see order_current_stream_after).  After composite(), sc.frame is complete once the
+    context's stream has been waited for (ctx.synchronize(), or an event on it).
     """
 
     def __init__(self, scene: api.Scene, cam: api.Camera, width: int, height: int, rank: int, world: int,
@@ -91,10 +121,14 @@ class SparseComposite:
     def gather(self):
         if self.slot_elems == 0:
             return  # nothing on screen: rank 0's frame is already complete
+        if self.planes.is_cuda:
+            order_current_stream_after(self.scene.ctx)  # the collective reads what the draw wrote
         if self.rank == 0:
             dist.gather(self.planes, self._parts, dst=0)
         else:
             dist.gather(self.planes, None, dst=0)
+        if self.planes.is_cuda:
+            order_context_stream_after_current(self.scene.ctx)  # the copy (and the next draw) follow the collective
 
     def scatter_received(self):
         if self.rank == 0 and self.slot_elems:
@@ -118,9 +152,10 @@ class SparseCompositeBatch:
             cb.composite(k)     # every rank: one gather; rank 0 also copies the received tiles into cb.frames[k]
         cb.frames[k]            # rank 0: [frames, 3, h*w] int32 planes (colour, depth bits, primitive id)
 
-    The draws of set k run on frame slot k of the scene's context; the gather and the copy run on torch's current
-    stream, which must be the context's stream.  A set's buffers are drawn into again only after its composite has
-    finished (the slot's stream waits for an event recorded behind the composite).
+    The draws of set k run on frame slot k of the scene's context, the copy of received tiles on the context's stream
+    and the gather on torch's current stream (ordered against the context's stream with events on the device when
+    they differ).  A set's buffers are drawn into again only after its composite has finished (the slot's stream
+    waits for an event recorded behind the composite).
     """
 
     def __init__(self, scene: api.Scene, cam: api.Camera, width: int, height: int, rank: int, world: int,
@@ -166,13 +201,15 @@ class SparseCompositeBatch:
     def gather(self, k: int, n: int | None = None):
         """The collective of set k on torch's current stream, behind the set's draws."""
         n = self.nframes if n is None else n
-        self.scene.ctx.frames_join()
+        self.scene.ctx.frames_join()  # the context's stream waits for the slots' draws
         if self.slot_elems == 0:
             return  # nothing on screen: rank 0's frames are already complete
+        order_current_stream_after(self.scene.ctx)
         if self.rank == 0:
             dist.gather(self.planes[k][:n], [self.gathered[k][r, :n] for r in range(self.world)], dst=0)
         else:
             dist.gather(self.planes[k][:n], None, dst=0)
+        order_context_stream_after_current(self.scene.ctx)
 
     def scatter_received(self, k: int, n: int | None = None):
         """Rank 0: copy the other ranks' tiles of set k into its frames (all planes of all frames in one launch);
@@ -182,7 +219,7 @@ class SparseCompositeBatch:
             s, F = self.slot_elems, self.nframes
             self.scene.ctx.deinterleave_sparse(self.prm0, self.rect, self.gathered[k].data_ptr(), F * 3 * s, s, 3 * n,
                                                self.frames[k].data_ptr(), self.width * self.height)
-        self._done[k].record()
+        self._done[k].record(torch.cuda.ExternalStream(self.scene.ctx.stream))  # behind the copy on the context's stream
         self.slot_streams[k].wait_event(self._done[k])
 
     def composite(self, k: int, n: int | None = None):

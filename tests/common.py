@@ -83,3 +83,70 @@ def pulled_back_camera(cam, distance, height=0.11):
     """The reference camera moved back along +z so that a grid of instances fits the view (same roll and lens)."""
     cam.view[12], cam.view[13], cam.view[14] = 0.0, float(np.float32(height)), float(-np.float32(distance))
     return cam
+
+
+def oracle_params(oracle, prm):
+    """The oracle's params for a draw: the same frame without the flags that only choose a GPU kernel."""
+    import renderer_amd as R
+    return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays,
+                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL | R.BLOCKS), prm.seed, ao_tmax=prm.ao_tmax)
+
+
+def planes_to_frame(planes, w, h):
+    """[3, h*w] int32 planes (colour, depth bits, primitive id) on the host -> (colour u8, depth f32, primid u32)."""
+    return (planes[0].view(np.uint8).reshape(h, w, 4), planes[1].view(np.float32).reshape(h, w),
+            planes[2].view(np.uint32).reshape(h, w))
+
+
+def sparse_composite_single_gpu(scene, ctx, cam, w, h, nranks, tile, **kw):
+    """The sparse composite with the ranks played one after another on this GPU: rank 0 renders into the frame,
+    the other ranks' slot buffers are laid out as the gather would deliver them, inv_deinterleave_sparse finishes."""
+    import torch
+
+    import renderer_amd as R
+    flags = kw.pop("flags", 0) | R.SPARSE
+    rect = scene.hit_rect(cam, w, h)
+    prm = [R.make_params(w, h, flags=flags, tile=tile, rank=r, nranks=nranks, **kw) for r in range(nranks)]
+    grid, n, _ = R.sparse_layout(prm[1], rect)
+    frame = torch.full((3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    gathered = torch.full((nranks, 3, max(n, 1)), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
+    for r in range(nranks):
+        o = frame if r == 0 else gathered[r]
+        scene.render_device(cam, prm[r], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    ctx.deinterleave_sparse(prm[0], rect, gathered.data_ptr(), 3 * max(n, 1), max(n, 1), 3, frame.data_ptr(), h * w)
+    ctx.synchronize()
+    return planes_to_frame(frame.cpu().numpy(), w, h), rect, grid, n
+
+
+def dense_composite_single_gpu(scene, ctx, cam, w, h, nranks, tile, **kw):
+    """The dense composite with the ranks played one after another on this GPU: every rank renders its tile slots
+    into its part of the gather buffer, inv_deinterleave rebuilds the three row-major planes."""
+    import torch
+
+    import renderer_amd as R
+    prm = [R.make_params(w, h, tile=tile, rank=r, nranks=nranks, **kw) for r in range(nranks)]
+    npix, _ = R.tile_layout(prm[0])
+    gathered = torch.full((nranks, 3, npix), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
+    frame = torch.full((3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    for r in range(nranks):
+        o = gathered[r]
+        scene.render_device(cam, prm[r], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    for k in range(3):
+        ctx.deinterleave(prm[0], gathered[0, k].data_ptr(), frame[k].data_ptr(), rank_stride=3 * npix)
+    ctx.synchronize()
+    return planes_to_frame(frame.cpu().numpy(), w, h)
+
+
+def check_lbvh(oracle, scene, xyzw, idx):
+    """The GPU build's sorted keys, order, hierarchy and boxes against the oracle's sequential build of the same mesh."""
+    got = scene.read_lbvh()
+    want = oracle.lbvh_build(xyzw, idx)
+    assert np.array_equal(got["morton"], want["morton"]), "sorted Morton keys"
+    assert np.array_equal(got["order"], want["order"]), "sorted order (stable: ties keep primitive order)"
+    assert np.array_equal(got["child"], want["child"]), "Karras hierarchy"
+    assert np.array_equal(got["parent"], want["parent"])
+    assert np.array_equal(got["leaf_parent"], want["leaf_parent"])
+    assert np.array_equal(got["box"], want["box"]), "refitted child boxes"  # min/max of inputs: exact
+    n = len(want["order"])
+    assert np.array_equal(np.sort(got["order"]), np.arange(n, dtype=got["order"].dtype))
+    assert (np.diff(got["morton"].astype(np.int64)) >= 0).all()

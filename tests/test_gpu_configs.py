@@ -1,0 +1,114 @@
+"""The benchmark configurations at their stated parameters, through the C ABI, against the CPU oracle.
+
+  config 3  bunny, 3840 x 2160, 16 jittered samples per pixel, seed 0: the whole frame, and the same frame as the
+            shards of 2 / 4 / 8 ranks put together again on this GPU (dense and sparse layouts)
+  config 4  32 x 32 = 1024 bunny instances flattened into one LBVH (5 087 232 triangles), 1080p: the LBVH against
+            the sequential build, the frame against the oracle
+  config 5  bunny, 1080p, 64 occlusion rays per hit pixel: as the shards of 8 ranks, and from close by (318 k hit
+            pixels, 20 M occlusion rays)
+
+Bar: bit-exact primitive id, depth bits and colour bytes.
+"""
+import numpy as np
+import pytest
+
+import common
+import objfmt
+import renderer_amd as R
+
+pytestmark = pytest.mark.gpu
+
+W4K, H4K = 3840, 2160
+FLAGS = R.LAMBERT | R.INVERT
+
+
+@pytest.fixture(scope="module")
+def bunny_scene(gpu_ctx, bunny_path):
+    scene = R.Scene(gpu_ctx, R.Mesh.load_obj(bunny_path))
+    yield scene
+    scene.close()
+
+
+@pytest.fixture(scope="module")
+def config3_frame(oracle, bunny_scene, bunny_mesh):
+    """The 4K / 16 spp frame from the oracle, checked once against the single-rank GPU frame."""
+    prm = R.make_params(W4K, H4K, spp=16, seed=0, flags=FLAGS)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(W4K, H4K), common.oracle_params(oracle, prm))
+    return want
+
+
+def test_config3_4k_16spp_against_oracle(bunny_scene, config3_frame):
+    prm = R.make_params(W4K, H4K, spp=16, seed=0, flags=FLAGS)
+    got = bunny_scene.render(R.camera_reference(W4K, H4K), prm)
+    common.assert_frames_equal(got, config3_frame, "config 3")
+    hits = got[2] != 0xFFFFFFFF
+    assert 100000 < int(hits.sum()) < 101500  # 100 580 from a double-precision rasteriser, give or take edge pixels
+    # sixteen samples: edge pixels hold blends, so the blue channel takes many more values than at one sample
+    assert len(np.unique(got[0][hits][:, 0])) > 150
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_config3_sparse_shards_reassemble(bunny_scene, gpu_ctx, config3_frame, nranks):
+    got, rect, grid, n = common.sparse_composite_single_gpu(bunny_scene, gpu_ctx, R.camera_reference(W4K, H4K), W4K, H4K,
+                                                            nranks, 32, spp=16, seed=0, flags=FLAGS)
+    common.assert_frames_equal(got, config3_frame, "config 3, sparse shards of %d ranks" % nranks)
+    assert n == -(-grid[2] * grid[3] // nranks) * 32 * 32
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_config3_dense_shards_reassemble(bunny_scene, gpu_ctx, config3_frame, nranks):
+    got = common.dense_composite_single_gpu(bunny_scene, gpu_ctx, R.camera_reference(W4K, H4K), W4K, H4K, nranks, 64,
+                                            spp=16, seed=0, flags=FLAGS)
+    common.assert_frames_equal(got, config3_frame, "config 3, dense shards of %d ranks" % nranks)
+
+
+def test_config4_1024_instances(oracle, gpu_ctx, bunny_path, bunny_mesh):
+    side = 32
+    tr = common.grid_translations(side)
+    scene = R.Scene(gpu_ctx, R.Mesh.load_obj(bunny_path), translations=tr)
+    try:
+        ntri, nnodes, _ = scene.counts()
+        assert (ntri, nnodes) == (1024 * 4968, 1024 * 4968 - 1)
+        fx, fi = common.flatten_instances(*bunny_mesh, tr)
+        common.check_lbvh(oracle, scene, fx, fi)
+        w, h = 1920, 1080
+        cam = common.pulled_back_camera(R.camera_reference(w, h), 0.27 * side)
+        ocam = oracle.Camera.from_buffer_copy(bytes(cam))
+        prm = R.make_params(w, h, flags=FLAGS)
+        got = scene.render(cam, prm)
+        want = oracle.render_bvh(fx, fi, ocam, common.oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "config 4")
+        hits = got[2] != 0xFFFFFFFF
+        assert hits.sum() > 300000 and len(np.unique(got[2][hits] // 4968)) == 1024  # every instance is seen
+        # the same frame as a batch of two on a frame slot (the form bench.py times for small scenes) and in parity mode
+        prm0 = R.make_params(w, h)
+        got0 = scene.render(cam, prm0)
+        want0 = oracle.render_bvh(fx, fi, ocam, common.oracle_params(oracle, prm0))
+        common.assert_frames_equal(got0, want0, "config 4, parity mode")
+    finally:
+        scene.close()
+        gpu_ctx.trim()  # 0.6 GB of build scratch
+
+
+def test_config5_ao64_as_shards_of_8_ranks(oracle, bunny_scene, gpu_ctx, bunny_mesh):
+    w, h = 1920, 1080
+    prm = R.make_params(w, h, ao_rays=64, flags=FLAGS)
+    want = oracle.render_bvh(*bunny_mesh, oracle.camera_reference(w, h), common.oracle_params(oracle, prm))
+    got, _, _, _ = common.sparse_composite_single_gpu(bunny_scene, gpu_ctx, R.camera_reference(w, h), w, h, 8, 32,
+                                                      ao_rays=64, flags=FLAGS)
+    common.assert_frames_equal(got, want, "config 5, sparse shards of 8 ranks")
+    got = common.dense_composite_single_gpu(bunny_scene, gpu_ctx, R.camera_reference(w, h), w, h, 8, 64, ao_rays=64,
+                                            flags=FLAGS)
+    common.assert_frames_equal(got, want, "config 5, dense shards of 8 ranks")
+
+
+def test_config5_ao64_from_close_by(oracle, bunny_scene, bunny_mesh):
+    """Eye 0.3 from the model: the bunny fills the frame, 64 occlusion rays for each of some 318 000 hit pixels."""
+    w, h = 1920, 1080
+    cam = R.camera_reference(w, h)
+    cam.view[12], cam.view[13], cam.view[14] = 0.0, 0.11, -0.3
+    prm = R.make_params(w, h, ao_rays=64, flags=FLAGS)
+    got = bunny_scene.render(cam, prm)
+    want = oracle.render_bvh(*bunny_mesh, oracle.Camera.from_buffer_copy(bytes(cam)), common.oracle_params(oracle, prm))
+    common.assert_frames_equal(got, want, "config 5 from close by")
+    assert int((got[2] != 0xFFFFFFFF).sum()) > 300000

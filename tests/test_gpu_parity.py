@@ -20,9 +20,7 @@ def bunny_scene(gpu_ctx, bunny_path):
     scene.close()
 
 
-def _oracle_params(oracle, prm):
-    return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays,
-                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL | R.BLOCKS), prm.seed, ao_tmax=prm.ao_tmax)
+_oracle_params = common.oracle_params
 
 
 def test_vertex_stage_matches_oracle(oracle, bunny_scene, bunny_mesh):
@@ -174,24 +172,7 @@ def test_tile_sharding_and_deinterleave(bunny_scene, gpu_ctx, nranks, tile):
     assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full[2])
 
 
-def _sparse_composite_single_gpu(scene, ctx, cam, w, h, nranks, tile, **kw):
-    """The sparse composite with the ranks played one after another on this GPU: rank 0 renders into the frame,
-    the other ranks' slot buffers are laid out as the gather would deliver them, inv_deinterleave_sparse finishes."""
-    import torch
-    flags = kw.pop("flags", 0) | R.SPARSE
-    rect = scene.hit_rect(cam, w, h)
-    prm = [R.make_params(w, h, flags=flags, tile=tile, rank=r, nranks=nranks, **kw) for r in range(nranks)]
-    grid, n, _ = R.sparse_layout(prm[1], rect)
-    frame = torch.full((3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
-    gathered = torch.full((nranks, 3, max(n, 1)), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
-    for r in range(nranks):
-        o = frame if r == 0 else gathered[r]
-        scene.render_device(cam, prm[r], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
-    ctx.deinterleave_sparse(prm[0], rect, gathered.data_ptr(), 3 * max(n, 1), max(n, 1), 3, frame.data_ptr(), h * w)
-    ctx.synchronize()
-    f = frame.cpu().numpy()
-    return (f[0].view(np.uint8).reshape(h, w, 4), f[1].view(np.float32).reshape(h, w),
-            f[2].view(np.uint32).reshape(h, w)), rect, grid, n
+_sparse_composite_single_gpu = common.sparse_composite_single_gpu
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -602,18 +583,7 @@ def test_errors(bunny_scene):
     assert e.value.code == R.api.ERR_UNSUPPORTED
 
 
-def _check_lbvh(oracle, scene, xyzw, idx):
-    got = scene.read_lbvh()
-    want = oracle.lbvh_build(xyzw, idx)
-    assert np.array_equal(got["morton"], want["morton"]), "sorted Morton keys"
-    assert np.array_equal(got["order"], want["order"]), "sorted order (stable: ties keep primitive order)"
-    assert np.array_equal(got["child"], want["child"]), "Karras hierarchy"
-    assert np.array_equal(got["parent"], want["parent"])
-    assert np.array_equal(got["leaf_parent"], want["leaf_parent"])
-    assert np.array_equal(got["box"], want["box"]), "refitted child boxes"  # min/max of inputs: exact
-    n = len(want["order"])
-    assert sorted(got["order"].tolist()) == list(range(n))
-    assert (np.diff(got["morton"].astype(np.int64)) >= 0).all()
+_check_lbvh = common.check_lbvh
 
 
 def test_lbvh_structure_matches_the_sequential_restatement(oracle, bunny_scene, bunny_mesh):

@@ -157,9 +157,17 @@ def test_tile_layout():
     assert npix == 46340 * 46340 and len(ids) == 725 * 725
     npix, _ = R.tile_layout(R.make_params(65535, 32767, tile=1024, rank=5, nranks=7))
     assert npix == -(-(64 * 32) // 7) * 1024 * 1024
-    for w, h in ((46341, 46341), (65536, 32768), (0xFFFFFFFF, 0xFFFFFFFF)):
+    for w, h in ((46341, 46341), (65536, 32768), (0xFFFFFFFF, 0xFFFFFFFF), (65537, 1), (1, 70000), (0x80000000, 1)):
         with pytest.raises(R.InvertError) as e:
             R.tile_layout(R.make_params(w, h))
+        assert e.value.code == api.ERR_ARG
+    # bounds on what the kernels loop over or divide by: samples per pixel, ranks (a rank count near 2^32 would wrap
+    # the slot arithmetic to an empty frame)
+    R.tile_layout(R.make_params(64, 64, spp=4096))
+    R.tile_layout(R.make_params(64, 64, rank=65535, nranks=65536))
+    for bad in (dict(spp=4097), dict(spp=0xFFFFFFFF), dict(nranks=65537), dict(rank=1, nranks=0xFFFFFFFF)):
+        with pytest.raises(R.InvertError) as e:
+            R.tile_layout(R.make_params(64, 64, **bad))
         assert e.value.code == api.ERR_ARG
 
 
