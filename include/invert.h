@@ -155,6 +155,16 @@ int inv_vertex_shader(inv_scene* scene, const inv_camera* cam, float* clip4, flo
  * triangle (cull BACK / front CLOCKWISE, depth LESS against a 1.0 clear, lower primitive wins ties:
  * src/invert.cpp:1331-1337, 1380-1385), its depth and its colour (src/shader.slang:27, 31-36) stored as sRGB8. */
 int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out);
+/* inv_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same draw, same results, on the context's
+ * stream; it calls no hipMalloc / hipFree: the occlusion queue, which inv_render allocates on first use, lives in a
+ * static device array of the library (INV_NOALLOC_QUEUE_PIXELS records, 13.6 MB per GPU, held until the process
+ * ends).  Limits: out->on_device must be 1 (INV_ERR_ARG otherwise); with ao_rays > 0 the hit rectangle of the frame
+ * (inv_scene_hit_rect) must hold at most INV_NOALLOC_QUEUE_PIXELS pixels (INV_ERR_ARG otherwise, nothing is drawn).
+ * Every call on a GPU shares that GPU's array: calls with ao_rays > 0 that overlap on one GPU (other contexts,
+ * other threads, other streams) race; calls on one context's stream are ordered and safe. */
+#define INV_NOALLOC_QUEUE_PIXELS 262144u
+int inv_render_noalloc(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out);
 
 /* ---- frames in flight ------------------------------------------------------------------------------------------ */
 /* The reference keeps MAX_FRAMES_IN_FLIGHT = 2 frames in flight (src/invert.cpp:241): drawFrame waits for the fence

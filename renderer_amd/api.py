@@ -27,7 +27,7 @@ SYMBOLS = (
     "inv_mesh_indices", "inv_mesh_pin", "inv_mesh_destroy",
     "inv_camera_reference", "inv_camera_turntable",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
-    "inv_vertex_shader", "inv_render", "inv_tile_layout", "inv_deinterleave",
+    "inv_vertex_shader", "inv_render", "inv_render_noalloc", "inv_tile_layout", "inv_deinterleave",
     "inv_render_batch", "inv_render_in_flight", "inv_frame_wait", "inv_frames_join", "inv_frame_stream",
     "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
     "inv_write_ppm", "inv_write_png", "inv_write_pfm", "inv_write_primid",
@@ -104,6 +104,7 @@ def lib():
     L.inv_scene_read_lbvh.argtypes = [vp] + [vp] * 6
     L.inv_vertex_shader.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int]
     L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
+    L.inv_render_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_render_in_flight.argtypes = [vp, C.c_uint32, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_render_batch.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.inv_frame_wait.argtypes = [vp, C.c_uint32]
@@ -391,6 +392,11 @@ class Scene:
         rc = lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(self._dev_out))
         if rc:
             _chk(rc)
+
+    def render_noalloc(self, cam: Camera, prm: Params, color_ptr: int = 0, depth_ptr: int = 0, primid_ptr: int = 0):
+        """inv_render_noalloc: the draw into device buffers without any device allocation (static occlusion queue)."""
+        out = Outputs(color_ptr or None, depth_ptr or None, primid_ptr or None, 1)
+        _chk(lib().inv_render_noalloc(self._h, C.byref(cam), C.byref(prm), C.byref(out)))
 
     def render_in_flight(self, slot: int, cam: Camera, prm: Params, color_ptr: int = 0, depth_ptr: int = 0,
                          primid_ptr: int = 0):

@@ -41,6 +41,18 @@ static int hip_fail(hipError_t e, const char* what) {
 
 using namespace inv;
 
+// ---- device memory of the entry point that allocates nothing (inv_render_noalloc) ----------------------------
+// The occlusion queue of a draw (256-byte header with the counter, then per queued pixel a 48-byte record and a
+// 4-byte accumulator) normally comes from hipMalloc on first use.  Callers that cannot allocate (HIP graph capture,
+// serving loops) get it from this array instead: part of the code object, so every GPU the library runs on holds
+// its own copy from the moment the library is loaded there until the process ends.  The name below is a host-side
+// stand-in, not a device address: host code uses the per-device pointer hipGetSymbolAddress returns.
+constexpr uint64_t kNoAllocQueueCap = INV_NOALLOC_QUEUE_PIXELS;       // queued pixels
+constexpr size_t kNoAllocBytes = 256 + kNoAllocQueueCap * (48 + 4); // 13 631 744 + 256 bytes
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+constexpr int kNoAllocMaxDevices = 64;
+static void* g_noalloc_ptr[kNoAllocMaxDevices]; // per device: where that GPU's copy of `scratch` lives
+
 struct inv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -54,6 +66,7 @@ struct inv_ctx {
     void* build_scratch = nullptr;
     size_t build_scratch_bytes = 0;
 
+    unsigned char* noalloc = nullptr; // this GPU's copy of `scratch` (inv_render_noalloc)
     uint32_t live_scenes = 0;         // scenes built on this context and not yet destroyed
 };
 
@@ -187,6 +200,19 @@ int inv_ctx_create(int device, void* hip_stream, inv_ctx** out) {
     inv_ctx* c = new (std::nothrow) inv_ctx;
     if (!c) return fail(INV_ERR_NOMEM, "inv_ctx_create: out of memory");
     c->device = device;
+    // once per device, with that device current: each GPU holds the array at its own address
+    if (device < kNoAllocMaxDevices) {
+        if (!g_noalloc_ptr[device]) {
+            void* p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p) {
+                delete c;
+                return hip_fail(e != hipSuccess ? e : hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)");
+            }
+            g_noalloc_ptr[device] = p;
+        }
+        c->noalloc = (unsigned char*)g_noalloc_ptr[device];
+    }
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -584,12 +610,28 @@ int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_param
     return INV_OK;
 }
 
+// With `noalloc` the draw takes its occlusion queue from the context's copy of `scratch` and refuses whatever would
+// need an allocation (host attachments, more queued pixels than the array holds).
 int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_camera* cam, const inv_params* params,
-              const inv_outputs* out) {
+              const inv_outputs* out, bool noalloc = false) {
     inv_ctx* ctx = scene->ctx;
     FrameK f;
     int rc = prepare_frame(scene, cam, params, &f);
     if (rc != INV_OK) return rc;
+    if (noalloc) {
+        if (!out->on_device)
+            return fail(INV_ERR_ARG, "inv_render_noalloc: attachments must be device pointers (host attachments need staging memory)");
+        if (!ctx->noalloc) return fail(INV_ERR_UNSUPPORTED, "inv_render_noalloc: this device index has no static scratch memory");
+        // only pixels of the hit rectangle can be queued
+        const uint64_t rect_px = (uint64_t)(f.rx1 - f.rx0) * (f.ry1 - f.ry0);
+        if (params->ao_rays && std::min<uint64_t>(rect_px, f.npix) > kNoAllocQueueCap) {
+            char buf[200];
+            std::snprintf(buf, sizeof buf,
+                          "inv_render_noalloc: up to %llu pixels can be hit, the static occlusion queue holds %llu; use inv_render",
+                          (unsigned long long)std::min<uint64_t>(rect_px, f.npix), (unsigned long long)kNoAllocQueueCap);
+            return fail(INV_ERR_ARG, buf);
+        }
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     Outputs dev = {nullptr, nullptr, nullptr};
     if (out->on_device) {
@@ -607,7 +649,17 @@ int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_
         if (out->primid) dev.primid = (uint32_t*)fs.stage[2];
     }
     AoK ao = {0, 0.0f, nullptr, nullptr, nullptr};
-    if (params->ao_rays) {
+    if (params->ao_rays && noalloc) {
+        // same layout as the allocated queue, in this GPU's copy of the static array (its last call's contents are
+        // still there: the counter is cleared here, an accumulator by the lane that queues its record)
+        float* q = (float*)ctx->noalloc;
+        ao.rays = params->ao_rays;
+        ao.tmax = params->ao_tmax > 0.0f ? params->ao_tmax : scene->vertex_diag;
+        ao.count = (uint32_t*)q;
+        ao.queue = q + 64;
+        ao.acc = (uint32_t*)(ao.queue + (size_t)kNoAllocQueueCap * 12);
+        HIP_TRY(hipMemsetAsync(ao.count, 0, 256, stream));
+    } else if (params->ao_rays) {
         if (f.npix > fs.ao_cap) { // 256-byte header (counters), then at most one 48-byte record and one
             HIP_TRY(hipStreamSynchronize(stream)); // 4-byte accumulator per pixel; an earlier draw may still use the old queue
             dfree(fs.ao_queue);
@@ -660,6 +712,11 @@ int flight_stream(inv_ctx* ctx, uint32_t slot, hipStream_t* s) {
 int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out) {
     if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render: null argument");
     return render_on(scene, scene->ctx->stream, scene->main, cam, params, out);
+}
+
+int inv_render_noalloc(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out) {
+    if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render_noalloc: null argument");
+    return render_on(scene, scene->ctx->stream, scene->main, cam, params, out, true);
 }
 
 // ---- frames in flight ----------------------------------------------------------------------------------
