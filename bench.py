@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s on the 1080p bunny (primary rays + Lambert shade + invert post-pass).
 
+Every frame of the timed region is written to HBM: the frames in flight rotate through enough attachment sets
+(over 1 GB, four times the 256 MB Infinity Cache in front of HBM) that no set is still cached when it is drawn into
+again, so `value` and `roofline` are HBM figures.
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 One step = one batch of --frames-per-step (default 64) frames of the workload rendered through the C ABI
@@ -90,6 +94,24 @@ def pmc_traffic(workload, world, kernel, frames_per_launch):
     return best
 
 
+def pmc_valu(workload, world, kernel):
+    """VALU utilisation of `kernel` from the newest profiles/*_valu.json of this workload (tools/valu_summary.py
+    writes it from a rocprofv3 --pmc pass of this bench), or None."""
+    import glob
+    if world != 1:
+        return None
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu.json"))):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        k = doc.get("workloads", {}).get(workload, {}).get(kernel)
+        if k:
+            best = dict(k, source=os.path.basename(path))
+    return best
+
+
 def cpu_baseline(wl, camera, budget_s=10.0):
     """Time the CPU oracle on the same frame (bounded: whole frames until the budget is used)."""
     from oracle import oracle as O
@@ -128,8 +150,9 @@ def main():
                     help="a step is one batch of this many frames of the workload (a single frame lasts a few "
                          "microseconds: too little to time a handful of steps)")
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
-                    help="one GPU: frame slots the submissions are dealt to")
+    ap.add_argument("--frames-in-flight", type=int, default=None, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
+                    help="one GPU: frame slots the submissions are dealt to (default: 3 where frames share launches, "
+                         "2 where every frame is a launch of its own)")
     ap.add_argument("--frames-per-launch", type=int, default=4, choices=range(1, 9),
                     help="one GPU: frames per inv_render_batch submission (1 with --frames-in-flight 1: plain inv_render "
                          "on the context's stream)")
@@ -137,8 +160,14 @@ def main():
                     help="N > 1, sparse composite: frames per submission and per gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-passes", action="store_true",
-                    help="skip the passes after the timed region (roofline.alone, roofline.streaming): under a "
-                         "profiler the kernel statistics then cover the timed region and its warm-up only")
+                    help="skip the passes after the timed region (roofline.alone, roofline.infinity_cache_resident): "
+                         "under a profiler the kernel statistics then cover the timed region and its warm-up only")
+    ap.add_argument("--attachment-gb", type=float, default=1.0,
+                    help="one GPU: the frames in flight rotate through at least this much attachment memory (the "
+                         "Infinity Cache holds 0.256 GB), so that every frame is written to HBM")
+    ap.add_argument("--warmup-ms", type=float, default=50.0,
+                    help="warm up for at least this long (in addition to --warmup steps): a handful of steps of a few "
+                         "hundred microseconds would time the clock ramp")
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
     ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
                     help="N > 1: gather only the tiles that can contain hits (sparse) or the whole frame (dense)")
@@ -199,9 +228,9 @@ def main():
     ao_rays = wl.get("ao_rays", 0)
     sparse = world > 1 and args.composite == "sparse"
     gathered = frame = sc = None
-    fif = args.frames_in_flight if world == 1 else 1  # the composite of several ranks runs on the context's stream
     # frames per submission: occlusion rays and many samples per pixel are drawn frame by frame anyway
     fpl = args.frames_per_launch if world == 1 and not ao_rays and spp < 4 and side == 1 else 1
+    fif = (args.frames_in_flight or (3 if fpl > 1 else 2)) if world == 1 else 1  # the composite of several ranks runs on the context's stream
     slots_used = fif > 1 or fpl > 1  # else: plain inv_render on the context's stream
     cb = None
     grouped = sparse and args.composite_frames > 1
@@ -218,9 +247,13 @@ def main():
     else:
         prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
         npix, _ = R.tile_layout(prm)
-        # one buffer, three planes (colour, depth, primitive id), 4 bytes per pixel each
-        # attachments: one set (three planes: colour, depth, primitive id) per frame in flight
-        slot_planes = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif * fpl)]
+        # attachments: one set (three planes: colour, depth, primitive id; 4 bytes per pixel each) per frame in
+        # flight, times `rotate`: every slot goes round `rotate` groups of sets, so that the job streams through
+        # --attachment-gb of memory and no set is still in the Infinity Cache when it is drawn into again
+        rotate = 1
+        if world == 1 and slots_used:
+            rotate = max(1, -(-int(args.attachment_gb * 1e9) // (fif * fpl * 12 * npix)))
+        slot_planes = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif * fpl * rotate)]
         slot_ptr = [[p[i].data_ptr() for i in range(3)] for p in slot_planes]
         planes, ptr = slot_planes[0], slot_ptr[0]
         if world > 1 and rank == 0:
@@ -245,12 +278,12 @@ def main():
 
         # Submission k draws frames k*fpl .. on slot k % fif into that slot's attachment sets; the argument arrays
         # are built once (the host work of a draw -- camera inverse, hit rectangle, grid -- stays in the call).
-        drawn = set()  # attachment sets (indices into the list passed as ptrs) some submission draws into
+        drawn = set()  # attachment sets some submission draws into
+        last_set = [0]  # the set the last frame of the latest list of submissions goes to
 
-        def make_submissions(nframes, ptrs=None, rotate=1):
-            # ptrs: attachment sets to draw into (default: the fif * fpl sets of the timed region); with rotate = M
-            # every slot goes round M groups of fpl sets, so that M * fif * fpl sets are in use
-            ptrs = ptrs or slot_ptr
+        def make_submissions(nframes, rotate):
+            # with rotate = M every slot goes round M groups of fpl sets, so that M * fif * fpl sets are in use
+            ptrs = slot_ptr
             subs, k, i = [], 0, 0
             while i < nframes:
                 n = min(fpl, nframes - i)
@@ -259,11 +292,13 @@ def main():
                 subs.append((j, n, scene.make_batch([cams[(i + u) % len(cams)] if turntable else cam for u in range(n)],
                                                     [prm] * n, [ptrs[group * fpl + u] for u in range(n)])))
                 drawn.update(group * fpl + u for u in range(n))
+                last_set[0] = group * fpl + n - 1
                 i, k = i + n, k + 1
             return subs
 
-        submissions = make_submissions(nframes)
-        warm_submissions = make_submissions(nwarm)
+        warm_submissions = make_submissions(max(nwarm, fif * fpl * rotate), rotate)  # every set is touched once
+        submissions = make_submissions(nframes, rotate)
+        final_set = last_set[0]
 
     def run(subs):
         for j, n, batch in subs:
@@ -321,13 +356,26 @@ def main():
             if rank == 0:
                 RD.deinterleave_on_gpu(ctx, prm0, gathered, frame)
 
-    if grouped:
-        run_groups(warm_groups)
-    elif slots_used:
-        run(warm_submissions)
-    else:
-        for _ in range(nwarm):
-            step()
+    def warm_up():
+        if grouped:
+            run_groups(warm_groups)
+        elif slots_used:
+            run(warm_submissions)
+        else:
+            for _ in range(nwarm):
+                step()
+        torch.cuda.synchronize()
+
+    # --warmup steps, then more of the same until --warmup-ms have passed (every rank the same number of rounds)
+    t_warm, warm_rounds = time.perf_counter(), 0
+    while True:
+        warm_up()
+        warm_rounds += 1
+        go_on = torch.tensor([1.0 if (time.perf_counter() - t_warm) * 1e3 < args.warmup_ms else 0.0], device="cuda")
+        if world > 1:
+            dist.all_reduce(go_on, op=dist.ReduceOp.MAX)
+        if float(go_on[0]) == 0.0 or warm_rounds >= 10000:
+            break
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -381,24 +429,20 @@ def main():
         torch.cuda.synchronize()
         alone_ms = a0.elapsed_time(a1) / len(submissions)
 
-    # The attachment sets of the timed region (fif * fpl frames) are rewritten every few microseconds; while they fit
-    # the 256 MB Infinity Cache in front of HBM, part of the stores never has to reach HBM before it is overwritten.
-    # The same job through four times as many sets (far more than that cache holds) shows the rate without that help.
-    streaming = None
-    if slots_used and not turntable and not args.no_extra_passes:
-        rotate = 4
-        more = [torch.empty(3, npix, dtype=torch.int32, device="cuda") for _ in range(fif * fpl * (rotate - 1))]
-        all_ptr = slot_ptr + [[p[i].data_ptr() for i in range(3)] for p in more]
-        subs = make_submissions(nframes, all_ptr, rotate)
-        run(make_submissions(min(nframes, fif * fpl * rotate), all_ptr, rotate))  # touch every set once
+    # The same job through one group of sets per slot only (fif * fpl sets: 299 MB for the headline, less than the
+    # Infinity Cache could hold if the stores were kept there): the stores are non-temporal, so this should make no
+    # difference; reported to show that the timed region does not lean on that cache.
+    resident = None
+    if slots_used and rotate > 1 and not turntable and not args.no_extra_passes:
+        subs = make_submissions(nframes, 1)
+        run(make_submissions(fif * fpl, 1))
         torch.cuda.synchronize()
         ts = time.perf_counter()
         run(subs)
         torch.cuda.synchronize()
-        streaming = (time.perf_counter() - ts, len(all_ptr))
-        if not all(torch.equal(slot_planes[0], (slot_planes + more)[i]) for i in sorted(drawn)):
-            raise SystemExit("the extra attachment sets hold different frames: timing rejected")
-        del more
+        resident = (time.perf_counter() - ts, fif * fpl)
+    if slots_used and not turntable and not all(torch.equal(slot_planes[0], slot_planes[i]) for i in sorted(drawn)):
+        raise SystemExit("the attachment sets hold different frames: timing rejected")
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -424,10 +468,7 @@ def main():
             raise SystemExit("composited frame differs from the single-GPU frame: timing rejected")
 
     if world == 1 and slots_used:
-        j, n, _ = submissions[-1]
-        planes = slot_planes[j * fpl + n - 1]  # the attachments of the last frame
-        if not turntable and not all(torch.equal(planes, slot_planes[i]) for i in sorted(drawn) if i < len(slot_planes)):
-            raise SystemExit("the attachment sets hold different frames: timing rejected")
+        planes = slot_planes[final_set]  # the attachments of the timed region's last frame
     if rank == 0:
         final = frame if world > 1 else planes
         hit_pixels = int((final[2] != -1).sum()) if world == 1 or rank == 0 else 0
@@ -438,6 +479,8 @@ def main():
         alg_bytes = 12 * (npix if world > 1 else w * h) + scene_bytes  # per frame
         launch_bytes = alg_bytes * fpl                                 # per launch of the render kernel
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        kernel_name = ("k_render_brute" if args.brute_force else "k_render_tile_batch" if fpl > 1 and not ao_rays and spp < 4
+                       else "k_render_tile") + ("+k_ao" if ao_rays else "")
         result = {
             "metric": "Mrays/s (primary + AO) bunny @1080p, 1/2/4/8 MI355X; % HBM/VALU roofline",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -455,30 +498,35 @@ def main():
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0%s" % (
                                            args.composite, world, ", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
                                        if world > 1 else "1 GPU")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, world, "k_render_tile_batch" if fpl > 1 else "k_render_tile", fpl),
-                         "kernel": ("k_render_brute" if args.brute_force else "k_render_tile_batch" if fpl > 1 and not ao_rays and spp < 4
-                                    else "k_render_tile") + ("+k_ao" if ao_rays else ""),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes": launch_bytes, "frames_per_launch": fpl,
-                         # the same bytes over the frame time of the whole job (kernels of different slots overlap)
-                         "job": {"achieved": alg_bytes * nframes / elapsed / 1e9,
-                                 "frac": alg_bytes * nframes / elapsed / 1e9 / HBM_PEAK_GBS}},
+            # `achieved` = algorithmic bytes of the frames drawn / wall time of the timed region: launches of different
+            # frame slots overlap on the GPU, so the job's rate, not a launch's, is what the HBM interface sustained.
+            # Every frame goes to attachments that left the Infinity Cache long ago (config.attachment_mb).
+            "roofline": {"bound": "hbm", "achieved": alg_bytes * nframes / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes * nframes / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.workload, world, kernel_name.split("+")[0], fpl),
+                         "kernel": kernel_name, "algorithmic_bytes": launch_bytes, "frames_per_launch": fpl,
+                         # one launch of the kernel: a slot's span between two HIP events on its stream / its launches;
+                         # with several slots a launch shares the GPU with the other slots' launches
+                         "launch": {"kernel_ms": kernel_ms, "concurrent_launches": fif if slots_used else 1,
+                                    "achieved": achieved, "frac": achieved / HBM_PEAK_GBS}},
             "cpu_baseline": None,
         }
         set_mb = 12 * (w * h) / 1e6
         if world == 1:
             result["config"]["attachment_sets"] = len(slot_planes)
             result["config"]["attachment_mb"] = set_mb * len(slot_planes)  # against the 256 MB Infinity Cache
-        if streaming is not None:  # the same job through 4x as many attachment sets (more than the Infinity Cache holds)
-            st, nsets = streaming
-            result["roofline"]["streaming"] = {"attachment_sets": nsets, "attachment_mb": set_mb * nsets,
-                                               "ms_per_step": st / args.steps * 1e3, "us_per_frame": st / nframes * 1e6,
-                                               "value": rays_per_frame * nframes / st / 1e6,
-                                               "achieved": alg_bytes * nframes / st / 1e9,
-                                               "frac": alg_bytes * nframes / st / 1e9 / HBM_PEAK_GBS}
-        if alone_ms is not None:  # the same kernel when no other slot's kernel shares the GPU with it
+        if resident is not None:  # the same job through fif * fpl sets only: not an HBM figure if it differed
+            st, nsets = resident
+            result["roofline"]["infinity_cache_sized_sets"] = {
+                "attachment_sets": nsets, "attachment_mb": set_mb * nsets, "us_per_frame": st / nframes * 1e6,
+                "value": rays_per_frame * nframes / st / 1e6, "achieved": alg_bytes * nframes / st / 1e9,
+                "frac_of_hbm_peak": alg_bytes * nframes / st / 1e9 / HBM_PEAK_GBS}
+        if alone_ms is not None:  # the same launches when no other slot's launch shares the GPU with them
             result["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": launch_bytes / (alone_ms * 1e-3) / 1e9,
                                            "frac": launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # VALU side: utilisation from the newest committed rocprofv3 counter pass of this workload (the counters
+        # cannot be read inside this process), or None
+        result["roofline"]["valu"] = pmc_valu(args.workload, world, kernel_name.split("+")[-1])
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
             base, oracle_out, work = cpu_baseline(wl, cams[(nframes - 1) % len(cams)] if turntable else cam)
@@ -491,11 +539,10 @@ def main():
                 raise SystemExit("GPU output differs from the CPU oracle: timing rejected")
             base["outputs_match_gpu"] = True
             result["cpu_baseline"] = base
-            # VALU side of the roofline: flops of a per-ray LBVH traversal of this frame (the oracle's test counts;
-            # the tile kernel does fewer box tests than that) over the measured kernel time
-            tflops = work["flops"] * fpl / (kernel_ms * 1e-3) / 1e12
-            result["roofline"]["valu"] = {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": tflops / VALU_PEAK_TFLOPS, "oracle_traversal": work}
+            # not a utilisation: the arithmetic a per-ray LBVH traversal of this frame would do (the oracle's test
+            # counts: 20 flops per ray, 22 per box test, 51 per triangle test, 15 per shaded hit), for comparison with
+            # the instruction counts of the kernel's counter pass
+            result["cpu_baseline"]["oracle_traversal_work"] = work
         print(json.dumps(result))
     scene.close()
     ctx.close()

@@ -145,6 +145,13 @@ int inv_scene_destroy(inv_scene* scene);
 int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uint32_t* child, uint32_t* parent,
                         uint32_t* leaf_parent, float* box);
 
+/* The scene's fine cut, which the per-frame binning pass reads instead of walking the tree: every subtree (or single
+ * leaf) of at most 16 sorted leaves whose parent covers more, as 8 floats per record: box lo.xyz, first sorted leaf
+ * (uint32 bits), box hi.xyz, leaf count (uint32 bits); in no particular order.  *nrecords is the number of records
+ * the scene holds (0: none -- fewer than 17 triangles, or a tree too unbalanced for the array); at most `cap` are
+ * copied.  `records` may be NULL. */
+int inv_scene_read_fine_cut(inv_scene* scene, float* records, uint32_t cap, uint32_t* nrecords);
+
 /* ---- the vertex stage on its own ---------------------------------------------------------------------------- */
 /* vertexShader (src/shader.slang:22-29) over every vertex of the scene's mesh: clip = P*(V*(M*(pos,1))) as three
  * successive products, colour = (1, 1, 10*pos.z).  clip4: nv*4 floats, color3: nv*3 floats (either may be NULL). */

@@ -26,7 +26,7 @@ SYMBOLS = (
     "inv_mesh_load_obj", "inv_mesh_load_obj_general", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
     "inv_mesh_indices", "inv_mesh_pin", "inv_mesh_destroy",
     "inv_camera_reference", "inv_camera_turntable",
-    "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh",
+    "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh", "inv_scene_read_fine_cut",
     "inv_vertex_shader", "inv_render", "inv_render_noalloc", "inv_tile_layout", "inv_deinterleave",
     "inv_render_batch", "inv_render_in_flight", "inv_frame_wait", "inv_frames_join", "inv_frame_stream",
     "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
@@ -102,6 +102,7 @@ def lib():
     L.inv_scene_counts.argtypes = [vp, u32p, u32p, u64p]
     L.inv_scene_destroy.argtypes = [vp]
     L.inv_scene_read_lbvh.argtypes = [vp] + [vp] * 6
+    L.inv_scene_read_fine_cut.argtypes = [vp, vp, C.c_uint32, u32p]
     L.inv_vertex_shader.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int]
     L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_render_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
@@ -348,6 +349,15 @@ class Scene:
                                        out["child"].ctypes.data, out["parent"].ctypes.data,
                                        out["leaf_parent"].ctypes.data, out["box"].ctypes.data))
         return out
+
+    def read_fine_cut(self):
+        """The fine cut as (box lo [n,3], box hi [n,3], first sorted leaf [n], leaf count [n]); n = 0: the scene has none."""
+        n = C.c_uint32()
+        _chk(lib().inv_scene_read_fine_cut(self._h, None, 0, C.byref(n)))
+        rec = np.zeros((max(n.value, 1), 8), np.float32)
+        _chk(lib().inv_scene_read_fine_cut(self._h, rec.ctypes.data, n.value, C.byref(n)))
+        rec = rec[:n.value]
+        return rec[:, 0:3].copy(), rec[:, 4:7].copy(), rec[:, 3].copy().view(np.uint32), rec[:, 7].copy().view(np.uint32)
 
     def hit_rect(self, cam: Camera, width: int, height: int):
         """Pixel rectangle (x0, y0, x1, y1) outside which every pixel is background for this camera."""

@@ -91,6 +91,7 @@ struct FrameScratch {
     uint64_t stage_elems = 0;
     float* ao_queue = nullptr; // occlusion-pass queue (grow-only): 256-byte header with the counter, then records
     uint64_t ao_cap = 0;
+    BinMem bins; // bins of the binning pass (grow-only)
 };
 
 struct inv_scene {
@@ -115,7 +116,7 @@ void dfree(T*& p) {
 void free_device_scene(DeviceScene& d) {
     dfree(d.arena); // every array of the scene lives in this one allocation
     d.xyzw = nullptr, d.idx = nullptr, d.triA = d.triB = d.triC = nullptr;
-    d.morton = nullptr, d.order = d.child = d.parent = d.leaf_parent = nullptr, d.nodes = d.cut = d.cut_groups = nullptr;
+    d.morton = nullptr, d.order = d.child = d.parent = d.leaf_parent = nullptr, d.nodes = d.cut = d.cut_groups = d.fine = nullptr;
 }
 
 void free_frame_scratch(FrameScratch& fs) {
@@ -123,6 +124,8 @@ void free_frame_scratch(FrameScratch& fs) {
     fs.stage_elems = 0;
     dfree(fs.ao_queue);
     fs.ao_cap = 0;
+    dfree(fs.bins.base);
+    fs.bins.nbins = 0;
 }
 
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).
@@ -556,6 +559,19 @@ int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uin
     return INV_OK;
 }
 
+int inv_scene_read_fine_cut(inv_scene* scene, float* records, uint32_t cap, uint32_t* nrecords) {
+    if (!scene || !nrecords) return fail(INV_ERR_ARG, "inv_scene_read_fine_cut: null argument");
+    const DeviceScene& d = scene->d;
+    *nrecords = d.has_bvh ? d.nfine : 0u;
+    const uint32_t n = std::min(*nrecords, cap);
+    if (records && n) {
+        HIP_TRY(hipSetDevice(scene->ctx->device));
+        HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
+        HIP_TRY(hipMemcpy(records, d.fine, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    return INV_OK;
+}
+
 // ---- vertex stage ----------------------------------------------------------------------------------
 int inv_vertex_shader(inv_scene* scene, const inv_camera* cam, float* clip4, float* color3, int on_device) {
     if (!scene || !cam) return fail(INV_ERR_ARG, "inv_vertex_shader: scene or cam is null");
@@ -595,7 +611,11 @@ int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_param
         // Bits above the INV_* flags switch parts of the kernels off for timing experiments (tools/phase_timing.py,
         // tools/tile_stats.py) and make the images wrong: they are refused unless INV_TIMING_SWITCHES is set.
         constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE | INV_BLOCKS;
+#ifdef INV_TIMING_BUILD
         static const bool allow = std::getenv("INV_TIMING_SWITCHES") != nullptr;
+#else
+        constexpr bool allow = false; // the release kernels do not contain the switches
+#endif
         if ((params->flags & ~known) && !allow) return fail(INV_ERR_ARG, "draw: unknown bits in params.flags");
     }
     FrameK& f = *fk;
@@ -607,6 +627,20 @@ int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_param
     if (scene->d.has_bvh) hit_rect(f, scene->d.bbox, rect);
     f.rx0 = rect[0], f.ry0 = rect[1], f.rx1 = rect[2], f.ry1 = rect[3];
     if (f.flags & INV_SPARSE) apply_sparse_grid(rect, &f);
+    return INV_OK;
+}
+
+// Room for `nbins` bins in the scratch of a stream (grow-only, with some slack so that a moving camera does not
+// allocate every few frames); new memory is cleared once, after that the kernels keep the counters at zero.
+int ensure_bins(hipStream_t stream, FrameScratch& fs, uint64_t nbins) {
+    if (nbins <= fs.bins.nbins) return INV_OK;
+    HIP_TRY(hipStreamSynchronize(stream)); // an earlier draw may still use the old bins
+    dfree(fs.bins.base);
+    fs.bins.nbins = 0;
+    const uint64_t room = nbins + nbins / 4 + 64;
+    HIP_TRY(hipMalloc(&fs.bins.base, bin_mem_bytes(room)));
+    fs.bins.nbins = room;
+    HIP_TRY(hipMemsetAsync(fs.bins.base, 0, bin_mem_bytes(room), stream));
     return INV_OK;
 }
 
@@ -675,10 +709,14 @@ int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_
         HIP_TRY(hipMemsetAsync(ao.count, 0, 256, stream));
     }
     const bool brute = (params->flags & INV_BRUTE_FORCE) || !scene->d.has_bvh;
-    if (brute)
+    if (brute) {
         HIP_TRY(launch_render_brute(stream, f, scene->d, ao, dev));
-    else
-        HIP_TRY(launch_render_bvh(stream, f, scene->d, ao, dev));
+    } else {
+        // (the entry point that allocates nothing draws from the coarse cut: same pixels, no bins)
+        const uint32_t nbins = noalloc ? 0u : tile_bins_wanted(f, scene->d, dev, false);
+        if (nbins && (rc = ensure_bins(stream, fs, nbins)) != INV_OK) return rc;
+        HIP_TRY(launch_render_bvh(stream, f, scene->d, ao, dev, nbins ? &fs.bins : nullptr));
+    }
     HIP_TRY(launch_ao(stream, f, scene->d, ao, dev));
     if (!out->on_device) {
         if (out->color) HIP_TRY(hipMemcpyAsync(out->color, dev.color, f.npix * 4, hipMemcpyDeviceToHost, stream));
@@ -755,11 +793,19 @@ int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const in
     // the launch of those collected before it.  Everything runs on one stream, and the attachments do not overlap.
     // (A frame left alone is drawn as a single draw: that picks the variant that finishes one frame soonest.)
     uint32_t pending = 0, last = 0; // frames collected; index of the latest of them
+    uint64_t pending_bins = 0;      // bins their binning pass needs
     const auto flush = [&]() -> int {
         const uint32_t n = pending;
-        pending = 0;
+        const uint64_t nbins = pending_bins;
+        pending = 0, pending_bins = 0;
         if (n == 1) return render_on(scene, stream, *fs, &cams[last], &params[last], &outs[last]);
-        if (n) HIP_TRY(launch_render_batch(stream, fk, dev, n, scene->d));
+        if (n) {
+            if (nbins) {
+                const int rc = ensure_bins(stream, *fs, nbins);
+                if (rc != INV_OK) return rc;
+            }
+            HIP_TRY(launch_render_batch(stream, fk, dev, n, scene->d, nbins ? &fs->bins : nullptr));
+        }
         return INV_OK;
     };
     for (uint32_t i = 0; i < nframes; i++) {
@@ -768,6 +814,7 @@ int inv_render_batch(inv_scene* scene, uint32_t slot, uint32_t nframes, const in
         if (rc != INV_OK) return rc;
         const Outputs o = {(uint8_t*)outs[i].color, (float*)outs[i].depth, (uint32_t*)outs[i].primid};
         if (outs[i].on_device && params[i].ao_rays == 0 && tile_batchable(f, scene->d, o)) {
+            pending_bins += tile_bins_wanted(f, scene->d, o, true);
             dev[pending++] = o, last = i;
             if (pending == INV_BATCH_MAX && (rc = flush()) != INV_OK) return rc;
         } else {

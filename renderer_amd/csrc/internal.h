@@ -71,6 +71,9 @@ struct DeviceScene {
     float* cut = nullptr;          // kCutCap records of 8 floats: lo xyz, first leaf | node, hi xyz, leaf count
     float* cut_groups = nullptr;   // boxes of kCutGroup consecutive cut records: 8 floats each
     uint32_t ncut = 0;             // records in use
+    float* fine = nullptr;         // the fine cut: every subtree of at most kRangeMax leaves under a larger parent,
+                                   // 8 floats per record (lo xyz, first leaf, hi xyz, leaf count), in no particular order
+    uint32_t nfine = 0;            // records of the fine cut; 0: the scene has none (a few triangles, or too unbalanced)
     bool has_bvh = false;
     uint32_t height = 0;           // height of the root (a node over two leaves has height 1)
     float bbox[6] = {0, 0, 0, 0, 0, 0};
@@ -83,13 +86,26 @@ hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, c
 hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
                            const float* translations, uint32_t ninst, float* A, float* B, float* C, uint32_t stride);
 hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
-hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
+// Device memory for the bins of a frame's binning pass: `nbins` counters, then `nbins` lists of 256 entries.  The
+// counters are zero between draws (whoever allocates the memory clears all of it once; every traced block leaves
+// its counter at zero again).  One BinMem serves one stream at a time.
+struct BinMem {
+    void* base = nullptr;
+    uint64_t nbins = 0;
+};
+size_t bin_mem_bytes(uint64_t nbins);
+// Bins the draw of this frame would use (0: it starts from the scene's coarse cut and needs none).  `batch`: the
+// frame shares a launch with others.
+uint32_t tile_bins_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch);
+// `bins` may be null or too small: the draw then starts from the coarse cut (same pixels either way).
+hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out,
+                             const BinMem* bins);
 // Several frames of one scene in one launch of the tile kernel (at most INV_BATCH_MAX; every frame must be
 // tile_batchable: LBVH scene, default traversal, not the dense variant; no occlusion pass).
 #define INV_BATCH_MAX 8
 bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out);
 hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
-                               const DeviceScene& sc);
+                               const DeviceScene& sc, const BinMem* bins);
 // Occlusion pass over the records the primary kernel queued (ao.rays > 0).
 hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 hipError_t launch_deinterleave_sparse(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,

@@ -408,6 +408,47 @@ __device__ __forceinline__ void block_append(bool flag, uint32_t value, uint32_t
     __syncthreads(); // the next call overwrites s_wave
 }
 
+// The fine cut: every subtree (or single leaf) of at most kRangeMax leaves whose parent covers more.  These subtrees
+// hold every leaf exactly once; a record is 8 floats, (lo.xyz, first sorted leaf) (hi.xyz, leaf count), the box being
+// the child box the parent's node record carries.  The per-frame binning pass reads them instead of walking the tree.
+// A finished node emits the records of its small children; one counter update per workgroup (see block_append), so
+// the order of the records depends on scheduling: nothing reads them in order.  Call from every thread.
+template <int NT>
+__device__ __forceinline__ void emit_fine(bool finished, uint32_t c0, uint2 leaves, const float b0[6], const float b1[6],
+                                          float* __restrict__ fine, uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
+    __shared__ uint32_t s_wave[NT / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t gamma = c0 & 0x7FFFFFFFu;
+    const uint32_t n0 = gamma - leaves.x + 1u, n1 = leaves.y - gamma;
+    const bool big = finished && leaves.y - leaves.x + 1u > kRangeMax;
+    const bool f0 = big && n0 <= kRangeMax, f1 = big && n1 <= kRangeMax;
+    const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
+    if (lane == 0) s_wave[wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < NT / 64; w++) total += s_wave[w];
+        s_base = total ? atomicAdd(fine_count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = s_base;
+    for (uint32_t w = 0; w < wave; w++) at += s_wave[w];
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint32_t at0 = at + (uint32_t)__popcll(m0 & below), at1 = at + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & below);
+    if (f0 && at0 < fine_cap) {
+        float4* r = (float4*)fine + 2 * (size_t)at0;
+        r[0] = make_float4(b0[0], b0[1], b0[2], __uint_as_float(leaves.x));
+        r[1] = make_float4(b0[3], b0[4], b0[5], __uint_as_float(n0));
+    }
+    if (f1 && at1 < fine_cap) {
+        float4* r = (float4*)fine + 2 * (size_t)at1;
+        r[0] = make_float4(b1[0], b1[1], b1[2], __uint_as_float(gamma + 1u));
+        r[1] = make_float4(b1[3], b1[4], b1[5], __uint_as_float(n1));
+    }
+    __syncthreads(); // the next call overwrites s_wave
+}
+
 // First the part of the tree that needs no exchange between workgroups.  Internal node i covers a range of sorted
 // leaves that contains leaf i, so every node whose range lies inside one chunk of kChunk consecutive leaves has its
 // index, its leaves and all of its descendants inside that chunk: one workgroup per chunk finishes those nodes in
@@ -426,7 +467,9 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
                                                          float* __restrict__ union_box,
                                                          float* __restrict__ nodes, uint32_t* __restrict__ arrive,
                                                          uint32_t* __restrict__ next, uint32_t* __restrict__ next_count,
-                                                         uint32_t* __restrict__ finished_count) {
+                                                         uint32_t* __restrict__ finished_count,
+                                                         float* __restrict__ fine, uint32_t* __restrict__ fine_count,
+                                                         uint32_t fine_cap) {
     __shared__ float s_leaf[6][kChunk]; // boxes of the chunk's leaves
     __shared__ float s_box[6][kChunk];  // boxes of the internal nodes finished here
     __shared__ uint32_t s_sweep[kChunk]; // sweep that finished the node, kOpen while it waits
@@ -449,7 +492,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     bool open = valid && k0 < kChunk && k1 < kChunk;
     uint2 leaves = make_uint2(0u, 0u);
     if (valid) leaves = range[i];
-    float b0[6], b1[6], u[6];
+    float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0}, u[6];
     uint32_t height = kOpen;
     __syncthreads();
     for (uint32_t sweep = 1;; sweep++) {
@@ -486,6 +529,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
             ub[1] = make_float4(u[4], u[5], __uint_as_float(height), 0.0f);
         }
     }
+    emit_fine<(int)kChunk>(height != kOpen, c0, leaves, b0, b1, fine, fine_count, fine_cap);
     const bool crossing = valid && height == kOpen;
     uint32_t arrived = 0;
     if (crossing) {
@@ -528,9 +572,11 @@ __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, co
                                                const float4* __restrict__ TC, const uint32_t* __restrict__ child,
                                                const uint32_t* __restrict__ parent,
                                                const uint2* __restrict__ range, uint32_t node,
-                                               float* __restrict__ union_box, float* __restrict__ nodes) {
-    const uint32_t c0 = child[2 * (size_t)node], c1 = child[2 * (size_t)node + 1];
-    const uint2 leaves = range[node];
+                                               float* __restrict__ union_box, float* __restrict__ nodes, uint32_t& c0,
+                                               uint2& leaves, float b0[6], float b1[6]) {
+    c0 = child[2 * (size_t)node];
+    const uint32_t c1 = child[2 * (size_t)node + 1];
+    leaves = range[node];
     float l0[3], h0[3], l1[3], h1[3];
     uint32_t ht0, ht1;
     load_child_box(c0, TA, TB, TC, union_box, l0, h0, ht0);
@@ -544,6 +590,8 @@ __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, co
     float4* u = (float4*)union_box + 2 * (size_t)node;
     u[0] = make_float4(fminf(l0[0], l1[0]), fminf(l0[1], l1[1]), fminf(l0[2], l1[2]), fmaxf(h0[0], h1[0]));
     u[1] = make_float4(fmaxf(h0[1], h1[1]), fmaxf(h0[2], h1[2]), __uint_as_float(ht), 0.0f);
+#pragma unroll
+    for (int a = 0; a < 3; a++) b0[a] = l0[a], b0[3 + a] = h0[a], b1[a] = l1[a], b1[3 + a] = h1[a];
     return parent[node];
 }
 
@@ -555,13 +603,17 @@ __global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ 
                                                      const uint32_t* __restrict__ ready_count,
                                                      uint32_t* __restrict__ arrive, float* __restrict__ union_box,
                                                      float* __restrict__ nodes, uint32_t* __restrict__ next,
-                                                     uint32_t* __restrict__ next_count) {
+                                                     uint32_t* __restrict__ next_count, float* __restrict__ fine,
+                                                     uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
     // The level's size is read on the device, so the host can queue several levels without waiting for each.
     const uint32_t nready = *ready_count;
     for (uint32_t base = blockIdx.x * blockDim.x; base < nready; base += gridDim.x * blockDim.x) { // block-uniform
         const uint32_t q = base + threadIdx.x;
-        uint32_t up = 0xFFFFFFFFu;
-        if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes);
+        uint32_t up = 0xFFFFFFFFu, c0 = 0;
+        uint2 leaves = make_uint2(0u, 0u);
+        float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0};
+        if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes, c0, leaves, b0, b1);
+        emit_fine<256>(q < nready, c0, leaves, b0, b1, fine, fine_count, fine_cap);
         // the second child to arrive makes the parent ready for the next launch
         const bool second = up != 0xFFFFFFFFu && atomicAdd(&arrive[up], 1u) == 1u;
         block_append<256>(second, up, next, next_count);
@@ -605,7 +657,7 @@ __device__ __forceinline__ uint32_t block_ranks(bool f0, bool f1, uint32_t (*tot
 // nothing is read.  summary: [0] number of cut records (kCutUnfinished: refit not finished), [1..6] scene bounds,
 // [7] height of the root -- everything the host wants to know at the end of a build, in one place.
 constexpr uint32_t kCutUnfinished = 0xFFFFFFFFu;
-constexpr uint32_t kSummaryWords = 8;
+constexpr uint32_t kSummaryWords = 12; // [8]: records of the fine cut (counted by the refit kernels)
 
 __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restrict__ nodes, float* __restrict__ cut,
                                                           float* __restrict__ groups,
@@ -701,13 +753,18 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
 
 } // namespace
 
+// Records the fine cut may hold.  A tree over well spread keys has about n / 10 subtrees of at most kRangeMax leaves
+// under larger parents; badly unbalanced trees have up to n.  A build that needs more than this leaves the scene
+// without a fine cut (its draws then start from the coarse cut, as scenes of a few triangles do).
+static uint32_t fine_cap_for(uint32_t n) { return n / 4u + 1024u; }
 static uint32_t bounds_blocks_for(uint32_t n) { return std::min<uint32_t>((n + 255) / 256, 1024); }
 static uint32_t sort_tiles_for(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 
 size_t lbvh_keep_bytes(uint32_t n) {
     if (n < 2) return 0;
     const size_t sizes[] = {(size_t)n * 8, (size_t)n * 4, (size_t)(n - 1) * 8, (size_t)(n - 1) * 4, (size_t)n * 4,
-                            (size_t)(n - 1) * 64, (size_t)kCutCap * 32, (size_t)(kCutCap / kCutGroup) * 32};
+                            (size_t)(n - 1) * 64, (size_t)kCutCap * 32, (size_t)(kCutCap / kCutGroup) * 32,
+                            (size_t)fine_cap_for(n) * 32};
     size_t total = 0;
     for (size_t b : sizes) total += Arena::aligned(b);
     return total;
@@ -751,7 +808,10 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     sc.nodes = keep.take<float>((size_t)(n - 1) * 64);
     sc.cut = keep.take<float>((size_t)kCutCap * 32);
     sc.cut_groups = keep.take<float>((size_t)(kCutCap / kCutGroup) * 32);
-    if (!range || !sc.cut_groups) return hipErrorOutOfMemory; // the arenas were sized for something else
+    const uint32_t fine_cap = fine_cap_for(n);
+    sc.fine = keep.take<float>((size_t)fine_cap * 32);
+    sc.nfine = 0;
+    if (!range || !sc.cut_groups || !sc.fine) return hipErrorOutOfMemory; // the arenas were sized for something else
     float4 *A1 = (float4*)sc.triA, *B1 = (float4*)sc.triB, *C1 = (float4*)sc.triC;
 
     const float4* T0 = (const float4*)records;
@@ -785,10 +845,11 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
                        range);
     HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
     uint32_t* finished_in_chunks = ready_count + kMaxLevels + 1;
+    uint32_t* fine_count = ready_count + kMaxLevels + 2 + 8;
     const uint32_t nchunks = (n + kChunk - 1) / kChunk;
     hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, (const float4*)A1, (const float4*)B1,
                        (const float4*)C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, ready[0], ready_count,
-                       finished_in_chunks);
+                       finished_in_chunks, sc.fine, fine_count, fine_cap);
     HIP_RET(hipGetLastError());
     // The nodes that cross chunk boundaries: one launch per tree level; level L reads its size from ready_count[L] on
     // the device and appends the nodes that become ready to level L + 1.  The host does not know the tree's height:
@@ -807,7 +868,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
             const int cur = (int)(level & 1u);
             hipLaunchKernelGGL(k_refit_level, grid_level, blk, 0, s, (const float4*)A1, (const float4*)B1,
                                (const float4*)C1, sc.child, sc.parent, range, ready[cur], ready_count + level, arrive, union_box,
-                               sc.nodes, ready[cur ^ 1], ready_count + level + 1);
+                               sc.nodes, ready[cur ^ 1], ready_count + level + 1, sc.fine, fine_count, fine_cap);
         }
         hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
                            (const uint32_t*)(ready_count + level), (const float*)d_bbox, (const float*)union_box,
@@ -823,6 +884,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     for (uint32_t l = 0; l < level; l++) finished += level_count[l];
     if (finished != n - 1 || summary[0] == kCutUnfinished) return hipErrorUnknown; // every internal node must have been refitted
     sc.ncut = summary[0];
+    sc.nfine = summary[8] <= fine_cap ? summary[8] : 0u; // more than the array holds: no fine cut
     std::memcpy(sc.bbox, summary + 1, 24);
     sc.height = summary[7];
     sc.has_bvh = true;

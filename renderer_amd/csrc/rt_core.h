@@ -373,6 +373,27 @@ __device__ __forceinline__ void store_pixel(uint32_t* p, uint32_t v) {
     asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// The colour attachment's value of a pixel whose samples' linear colours add up to (sr, sg, sb).
+__device__ __forceinline__ uint32_t resolve_pixel(const FrameK& f, float sr, float sg, float sb, const float* T = kSrgbT) {
+    if (f.spp > 1) { // x / 1 is x: the resolve division is only needed for several samples
+        const float n = (float)f.spp;
+        sr = sr / n, sg = sg / n, sb = sb / n;
+    }
+    return pack_pixel(f.flags, sr, sg, sb, T);
+}
+
+// Sixteen bytes (four pixels of one attachment row) in one write-through store.  A four-byte write-through store is a
+// memory-side write of its own, so a traced block that stored its pixels one lane at a time paid several times the
+// price per byte that the clear pays; blocks and tiles therefore put their finished pixels together in LDS and store
+// them in whole 16-byte pieces (store_block_rows below).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#ifndef INV_PIXEL_MODS
+#define INV_PIXEL_MODS "sc1"
+#endif
+__device__ __forceinline__ void store_pixels4(uint32_t* p, u32x4_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off " INV_PIXEL_MODS ::"v"(p), "v"(v) : "memory");
+}
+
 // Resolve and store one pixel whose samples were traced by this lane.  sr/sg/sb are the summed linear
 // colours.  With ambient occlusion on (one sample per pixel) a hit pixel is queued for the occlusion pass,
 // which writes its colour, instead.  Every active lane of the wave must call this together.
@@ -389,13 +410,7 @@ __device__ __forceinline__ void finish_pixel(const FrameK& f, const AoK& ao, con
         ao_push(ao, push, o, n, sr, sg, sb, pix, oi);
         if (push) return;
     }
-    if (out.color) {
-        if (f.spp > 1) { // x / 1 is x: the resolve division is only needed for several samples
-            const float n = (float)f.spp;
-            sr = sr / n, sg = sg / n, sb = sb / n;
-        }
-        store_pixel((uint32_t*)out.color + oi, pack_pixel(f.flags, sr, sg, sb, T));
-    }
+    if (out.color) store_pixel((uint32_t*)out.color + oi, resolve_pixel(f, sr, sg, sb, T));
 }
 
 // Grid tile of a pixel; false when the pixel lies outside the tile grid the shards are dealt from.

@@ -38,8 +38,15 @@ namespace inv {
 
 namespace {
 
-// timing-only switches in the high flag bits (images are wrong when set; used by tools/phase_timing.py)
+// Timing-only switches in the high flag bits (images are wrong when set; used by tools/phase_timing.py and
+// tools/tile_stats.py).  They exist only in the library built with -DINV_TIMING_BUILD (make timing): in the release
+// build every test below is a compile-time false and the kernels carry neither the branches nor the stamps.
+#ifdef INV_TIMING_BUILD
 constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDebugSkipAll = 1u << 22, kDebugCounts = 1u << 23, kDebugSkipExact = 1u << 24, kDebugSkipFill = 1u << 25;
+#define INV_DBG(f, bits) (((f).flags & (bits)) != 0u)
+#else
+#define INV_DBG(f, bits) false
+#endif
 
 #ifndef INV_AO_REFILL
 #define INV_AO_REFILL 32
@@ -338,6 +345,42 @@ __device__ __forceinline__ bool out_index(const FrameK& f, uint32_t px, uint32_t
     return id % f.nranks == f.rank;
 }
 
+// A traced square of EDGE x EDGE pixels whose attachments can be stored in 16-byte pieces: the square lies inside the
+// frame, the frame's rows and the buffers allow 16-byte accesses (vec4), and the colour is final here (no occlusion
+// pass).  Block-uniform.  `o0` is the output index of the square's first pixel, `pitch` the output elements per row.
+template <uint32_t EDGE>
+__device__ __forceinline__ bool packed_square(const FrameK& f, int vec4, const AoK& ao, uint32_t tx0, uint32_t ty0,
+                                              uint64_t& o0, uint32_t& pitch) {
+    pitch = f.rowmajor ? f.w : f.tile;
+    o0 = 0;
+    if (!vec4 || ao.rays || tx0 + EDGE > f.w || ty0 + EDGE > f.h) return false;
+    return out_index(f, tx0, ty0, o0); // owned by this rank (a square lies in one grid tile)
+}
+
+// One attachment of a finished square from LDS (row-major EDGE x EDGE values) to memory, `lanes` = EDGE * EDGE / 4
+// consecutive lanes starting at lane `first`, 16 bytes each.
+template <uint32_t EDGE>
+__device__ __forceinline__ void store_square_rows(uint32_t* base, uint64_t o0, uint32_t pitch, const uint32_t* lds,
+                                                  uint32_t k /* 0 .. EDGE * EDGE / 4 - 1 */) {
+    constexpr uint32_t per_row = EDGE / 4u;
+    const uint32_t row = k / per_row, seg = k % per_row;
+    const u32x4_t v = *(const u32x4_t*)(lds + row * EDGE + seg * 4u);
+    store_pixels4(base + o0 + (uint64_t)row * pitch + seg * 4u, v);
+}
+
+// The clear values of a square nothing can hit.
+template <uint32_t EDGE>
+__device__ __forceinline__ void clear_square(const FrameK& f, const Outputs& out, uint64_t o0, uint32_t pitch, uint32_t k,
+                                             uint32_t which /* 0 colour, 1 depth, 2 primitive id */) {
+    constexpr uint32_t per_row = EDGE / 4u;
+    const uint32_t row = k / per_row, seg = k % per_row;
+    const uint64_t at = o0 + (uint64_t)row * pitch + seg * 4u;
+    const uint32_t bg = background_pixel(f.flags);
+    if (which == 0u && out.color) store_pixels4((uint32_t*)out.color + at, u32x4_t{bg, bg, bg, bg});
+    if (which == 1u && out.depth) store_pixels4((uint32_t*)out.depth + at, u32x4_t{0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u});
+    if (which == 2u && out.primid) store_pixels4(out.primid + at, u32x4_t{~0u, ~0u, ~0u, ~0u});
+}
+
 template <int NW, int CAP>
 struct TileLds {
     union {
@@ -364,6 +407,7 @@ struct TileLds {
     uint32_t rec_overflow; // more candidate records than the list holds: phase 3 runs in batches
     uint32_t rec_k[CAP]; // position of each record in the sorted triangle arrays
     float lambert[CAP];  // Lambert factor of each record's triangle
+    uint32_t px_out[3][64]; // the tile's finished pixels (colour, depth bits, primitive id), row-major 8 x 8
 };
 
 // Append `flag` lanes' values to an LDS list: one counter update per wave, lanes ranked by ballot.
@@ -383,27 +427,56 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                                            const float4* __restrict__ TA, const float4* __restrict__ TB,
                                            const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                            const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
-                                           uint32_t ncut, const AoK& ao, const Outputs& out) {
+                                           uint32_t ncut, uint32_t* __restrict__ bin_count,
+                                           const uint2* __restrict__ bin_list, uint32_t ntri, int vec4, const AoK& ao,
+                                           const Outputs& out) {
     constexpr uint32_t NT = NW * 64;
+    static_assert(NT == (uint32_t)kRangeCap, "one lane per entry of a bin");
+#ifndef INV_PACK_TILES
+#define INV_PACK_TILES 0
+#endif
+    // Tiles of dense scenes store their pixels in 16-byte pieces through LDS, as the 16x16 blocks do.  The sparse
+    // scenes' tiles do not: their rows are 32 bytes, and with the exchange the draw of the 1080p bunny took 11.9
+    // instead of 11.1 us (4K, 16 samples: 36.4 instead of 35.5 us per frame).
+    constexpr bool kPackTile = INV_PACK_TILES != 0 || BATCHED;
     constexpr int kTileCap = BATCHED ? kTileCapBatched : kTileCapSparse;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const float grow = 2.0f * f.pad;
-    if (f.flags & kDebugSkipAll) return;
+    if (INV_DBG(f, kDebugSkipAll)) return;
     const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 8u), (float)(ty0 + 8u), grow);
-    const bool stamps = (f.flags & kDebugCounts) && !(f.flags & kDebugSkipAfter2); // diagnostic build of the image
+    const bool stamps = INV_DBG(f, kDebugCounts) && !INV_DBG(f, kDebugSkipAfter2); // diagnostic build of the image
     unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
     if (stamps) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
-    //      is still a subtree after that is opened breadth-first ----
-    // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
-    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
-    float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
-    if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
-    if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.rec_overflow = 0, S.n_groups = 0;
+    // ---- phase 1, binned: the frame's binning pass (k_bin_ranges) has listed the leaf ranges whose boxes can touch
+    //      this tile; the list and its length arrive in one round trip (every lane fetches one entry whether the
+    //      list reaches that far or not), and the tile leaves the counter at zero for the next frame's pass ----
+    uint32_t bin_n = 0;
+    uint2 bin_e = make_uint2(0u, 0u);
+    if (bin_count) bin_n = __builtin_amdgcn_readfirstlane(*bin_count), bin_e = bin_list[tid]; // block-uniform
     const float srgb_entry = kSrgbT[tid & 255u]; // stored to LDS later: the load stays in flight behind the first steps
     if (tid < 64) S.best[tid] = kMissKey;
-    __syncthreads();
+    if (bin_count) {
+        if (tid == 0) {
+            S.n_front[0] = 0, S.n_front[1] = 0, S.n_rec = 0, S.rec_overflow = 0, S.n_groups = 0;
+            S.n_ranges = min(bin_n, (uint32_t)kRangeCap), S.overflow = bin_n > (uint32_t)kRangeCap;
+        }
+        if (tid < bin_n && tid < (uint32_t)kRangeCap) S.u.t.ranges[tid] = bin_e;
+        __syncthreads();
+        // only now: every wave has used the count it loaded (a wave that loaded after the reset would see zero)
+        if (tid == 0) *bin_count = 0u;
+    }
+    // ---- phase 1 from the coarse cut (scenes without a fine cut, draws without a binning pass): groups of cut
+    //      records, then the records of the surviving groups, one box per lane; whatever is still a subtree after
+    //      that is opened breadth-first ----
+    // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
+    const uint32_t ngroups = bin_count ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
+    float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
+    if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
+    if (!bin_count) {
+        if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.rec_overflow = 0, S.n_groups = 0;
+        __syncthreads();
+    }
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
         const uint32_t g = base + tid;
         bool in = false;
@@ -496,9 +569,13 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     const uint32_t px = tx0 + (lane & 7u), py = ty0 + (lane >> 3);
     uint64_t oi = 0;
     const bool valid = px < f.w && py < f.h && out_index(f, px, py, oi);
-    if (f.flags & kDebugSkipAfter1) return;
-    if (S.n_ranges == 0 && !S.overflow && !(f.flags & kDebugCounts)) { // nothing in this tile: clear values
-        if (wave == 0 && valid) {
+    if (INV_DBG(f, kDebugSkipAfter1)) return;
+    if (S.n_ranges == 0 && !S.overflow && !INV_DBG(f, kDebugCounts)) { // nothing in this tile: clear values
+        uint64_t sq0;
+        uint32_t sq_pitch;
+        if (kPackTile && packed_square<8u>(f, vec4, ao, tx0, ty0, sq0, sq_pitch)) { // in 16-byte pieces (block-uniform)
+            if (tid < 48u) clear_square<8u>(f, out, sq0, sq_pitch, tid & 15u, tid >> 4);
+        } else if (wave == 0 && valid) {
             if (out.depth) store_pixel((uint32_t*)out.depth + oi, 0x3F800000u); // 1.0f
             if (out.primid) store_pixel(out.primid + oi, 0xFFFFFFFFu);
             if (out.color) store_pixel((uint32_t*)out.color + oi, background_pixel(f.flags));
@@ -536,7 +613,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                 if (q < nslots) {
                     const uint2 rg = S.u.t.ranges[r0 + q / kRangeMax];
                     const uint32_t off = q % kRangeMax;
-                    if (off < rg.y) {
+                    if (off < rg.y && rg.x + off < ntri) { // (the second test never fails for a list built from this scene)
                         k2[u] = rg.x + off;
                         have[u] = true, A2[u] = TA[k2[u]], B2[u] = TB[k2[u]], C2[u] = TC[k2[u]];
                     }
@@ -598,8 +675,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
         return;
     }
 
-    if (f.flags & kDebugSkipAfter2) {
-        if ((f.flags & kDebugCounts) && valid && wave == 0) { // list sizes instead of an image
+    if (INV_DBG(f, kDebugSkipAfter2)) {
+        if (INV_DBG(f, kDebugCounts) && valid && wave == 0) { // list sizes instead of an image
             if (out.depth) out.depth[oi] = __uint_as_float(S.n_ranges);
             if (out.primid) out.primid[oi] = S.n_rec;
         }
@@ -685,7 +762,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                 inside |= (uint64_t)mt_inside_pair(ray, q[0], q[1], q[2], q[3], q[4]) << (2u * k);
             }
             // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
-            if (f.flags & kDebugSkipExact) inside = 0; // timing experiment only
+            if (INV_DBG(f, kDebugSkipExact)) inside = 0; // timing experiment only
             while (inside) {
                 const uint32_t i = (uint32_t)__ffsll((long long)inside) - 1u;
                 inside &= inside - 1ull;
@@ -729,6 +806,23 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
         }
         return;
     }
+    // whether the tile's pixels leave in 16-byte pieces through LDS (block-uniform; worked out only here, so that it
+    // does not occupy registers through the phases above)
+    uint64_t sq0;
+    uint32_t sq_pitch;
+    if (kPackTile && packed_square<8u>(f, vec4, ao, tx0, ty0, sq0, sq_pitch)) { // the first wave holds the tile's 64 pixels
+        if (wave == 0) {
+            S.px_out[0][lane] = resolve_pixel(f, sr, sg, sb, S.srgb);
+            S.px_out[1][lane] = (uint32_t)(first.key >> 32), S.px_out[2][lane] = (uint32_t)first.key;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t a = lane >> 4;
+            uint32_t* const base = a == 0u ? (uint32_t*)out.color : a == 1u ? (uint32_t*)out.depth : out.primid;
+            if (lane < 48u && base) store_square_rows<8u>(base, sq0, sq_pitch, S.px_out[a], lane & 15u);
+        }
+        return;
+    }
     if (wave != 0 || !valid) return;
     const uint32_t ws = first.key != kMissKey ? first.slot : 0u;
     if (batched)
@@ -762,6 +856,7 @@ struct BlockLds {
     uint32_t n_ranges;
     uint32_t n_rec;
     uint32_t overflow; // more subtrees, leaf ranges or records than the lists hold: per-lane traversal instead
+    uint32_t px_out[3][256]; // the block's finished pixels (colour, depth bits, primitive id), row-major 16 x 16
 };
 
 // One workgroup of four waves per 16x16 pixel block of the rectangle that can contain hits.  Phases 1 and 2 find the
@@ -774,25 +869,47 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
                                             const float4* __restrict__ TA, const float4* __restrict__ TB,
                                             const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                             const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
-                                            uint32_t ncut, const AoK& ao, const Outputs& out) {
+                                            uint32_t ncut, uint32_t* __restrict__ bin_count,
+                                            const uint2* __restrict__ bin_list, uint32_t ntri, int vec4, const AoK& ao,
+                                            const Outputs& out) {
     constexpr uint32_t NT = 256;
+    static_assert(NT == (uint32_t)kRangeCap, "one lane per entry of a bin");
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const float grow = 2.0f * f.pad;
-    if (f.flags & kDebugSkipAll) return;
+    if (INV_DBG(f, kDebugSkipAll)) return;
     const Frustum fr = make_frustum(f, (float)tx0, (float)ty0, (float)(tx0 + 16u), (float)(ty0 + 16u), grow);
-    const bool stamps = (f.flags & kDebugCounts) && !(f.flags & kDebugSkipAfter2); // diagnostic build of the image
+    const bool stamps = INV_DBG(f, kDebugCounts) && !INV_DBG(f, kDebugSkipAfter2); // diagnostic build of the image
     unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0, ta = 0, tb = 0, tc = 0;
     if (stamps) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- phase 1: groups of cut records, then the records of the surviving groups, one box per lane; whatever
-    //      is still a subtree after that is opened breadth-first ----
+    // ---- phase 1, binned: the frame's binning pass (k_bin_ranges) has listed the leaf ranges whose boxes can touch
+    //      this block; the list and its length arrive in one round trip (every lane fetches one entry whether the
+    //      list reaches that far or not), and the block leaves the counter at zero for the next frame's pass ----
+    uint32_t bin_n = 0;
+    uint2 bin_e = make_uint2(0u, 0u);
+    if (bin_count) bin_n = __builtin_amdgcn_readfirstlane(*bin_count), bin_e = bin_list[tid]; // block-uniform
+    const float srgb_entry = kSrgbT[tid]; // stored to LDS later: the load stays in flight behind the first steps
+    if (bin_count) {
+        if (tid == 0) {
+            S.n_front[0] = 0, S.n_front[1] = 0, S.n_rec = 0, S.n_groups = 0;
+            S.n_ranges = min(bin_n, (uint32_t)kRangeCap), S.overflow = bin_n > (uint32_t)kRangeCap;
+        }
+        if (tid < bin_n && tid < (uint32_t)kRangeCap) S.u.t.ranges[tid] = bin_e;
+        __syncthreads();
+        // only now: every wave has used the count it loaded (a wave that loaded after the reset would see zero)
+        if (tid == 0) *bin_count = 0u;
+    }
+    // ---- phase 1 from the coarse cut (scenes without a fine cut, draws without a binning pass): groups of cut
+    //      records, then the records of the surviving groups, one box per lane; whatever is still a subtree after
+    //      that is opened breadth-first ----
     // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
-    const uint32_t ngroups = (ncut + kCutGroup - 1u) / kCutGroup;
+    const uint32_t ngroups = bin_count ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
     float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
     if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
-    if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
-    const float srgb_entry = kSrgbT[tid]; // stored to LDS later: the load stays in flight behind the first steps
-    __syncthreads();
+    if (!bin_count) {
+        if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
+        __syncthreads();
+    }
     if (stamps) ta = __builtin_amdgcn_s_memtime();
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
         const uint32_t g = base + tid;
@@ -899,9 +1016,13 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
     const uint32_t px = tx0 + ((wave & 1u) << 3) + (lane & 7u), py = ty0 + ((wave >> 1) << 3) + (lane >> 3);
     uint64_t oi = 0;
     const bool valid = px < f.w && py < f.h && out_index(f, px, py, oi);
-    if (f.flags & kDebugSkipAfter1) return;
-    if (S.n_ranges == 0 && !S.overflow && !(f.flags & kDebugCounts)) { // nothing in this block: clear values
-        if (valid) {
+    if (INV_DBG(f, kDebugSkipAfter1)) return;
+    if (S.n_ranges == 0 && !S.overflow && !INV_DBG(f, kDebugCounts)) { // nothing in this block: clear values
+        uint64_t sq0;
+        uint32_t sq_pitch;
+        if (packed_square<16u>(f, vec4, ao, tx0, ty0, sq0, sq_pitch)) { // in 16-byte pieces (block-uniform)
+            if (wave < 3u) clear_square<16u>(f, out, sq0, sq_pitch, lane, wave);
+        } else if (valid) {
             if (out.depth) store_pixel((uint32_t*)out.depth + oi, 0x3F800000u); // 1.0f
             if (out.primid) store_pixel(out.primid + oi, 0xFFFFFFFFu);
             if (out.color) store_pixel((uint32_t*)out.color + oi, background_pixel(f.flags));
@@ -938,7 +1059,7 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
                 if (q < nslots) {
                     const uint2 rg = S.u.t.ranges[q / kRangeMax];
                     const uint32_t off = q % kRangeMax;
-                    if (off < rg.y) {
+                    if (off < rg.y && rg.x + off < ntri) { // (the second test never fails for a list built from this scene)
                         const uint32_t k = rg.x + off;
                         have[u] = true, A[u] = TA[k], B[u] = TB[k], C[u] = TC[k];
                     }
@@ -1001,8 +1122,8 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
         }
         return;
     }
-    if (f.flags & kDebugSkipAfter2) {
-        if ((f.flags & kDebugCounts) && valid) { // list sizes instead of an image
+    if (INV_DBG(f, kDebugSkipAfter2)) {
+        if (INV_DBG(f, kDebugCounts) && valid) { // list sizes instead of an image
             if (out.depth) out.depth[oi] = __uint_as_float(S.n_ranges);
             if (out.primid) out.primid[oi] = S.n_rec;
         }
@@ -1044,7 +1165,7 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
             }
             inside &= rel[c]; // a pair's other record may belong to other quadrants only, or (last pair) not exist
             // ... then the full test (depth, guard, key) only for those, each lane walking its own bits
-            if (f.flags & kDebugSkipExact) inside = 0; // timing experiment only
+            if (INV_DBG(f, kDebugSkipExact)) inside = 0; // timing experiment only
             while (inside) {
                 const uint32_t j = (uint32_t)c * 64u + (uint32_t)__ffsll((long long)inside) - 1u;
                 inside &= inside - 1ull;
@@ -1069,6 +1190,19 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
         }
         return;
     }
+    // whether the block's pixels leave in 16-byte pieces through LDS (block-uniform; worked out only here, so that it
+    // does not occupy registers through the phases above)
+    uint64_t sq0;
+    uint32_t sq_pitch;
+    if (packed_square<16u>(f, vec4, ao, tx0, ty0, sq0, sq_pitch)) { // every wave's quadrant into the block's image
+        const uint32_t li = ((((wave >> 1) << 3) | (lane >> 3)) << 4) | ((wave & 1u) << 3) | (lane & 7u);
+        S.px_out[0][li] = resolve_pixel(f, sr, sg, sb, S.srgb);
+        S.px_out[1][li] = (uint32_t)(first.key >> 32), S.px_out[2][li] = (uint32_t)first.key;
+        __syncthreads();
+        uint32_t* const base = wave == 0u ? (uint32_t*)out.color : wave == 1u ? (uint32_t*)out.depth : out.primid;
+        if (wave < 3u && base) store_square_rows<16u>(base, sq0, sq_pitch, S.px_out[wave], lane);
+        return;
+    }
     if (!valid) return;
     const uint32_t ws = first.key != kMissKey ? first.slot : 0u;
     finish_pixel(f, ao, out, oi, pix, ray0, first, S.u.t.rec[ws][1], S.u.t.rec[ws][2], sr, sg, sb, S.srgb);
@@ -1082,6 +1216,12 @@ struct TilePlan {
     uint32_t pixel_blocks;      // 32x8 pixel blocks of the frame (fill part without 16-byte stores)
     int vec4;                   // rows and addresses allow 16-byte stores
     uint32_t row4_magic;        // floor(2^32 / chunks per row)
+    // Bins of the frame's binning pass, one per traced block: bin_count[b] entries of bin_list[b * kRangeCap ...],
+    // each the (first sorted triangle, count) of a leaf range whose box can touch block b.  Null: no binning pass
+    // ran for this frame and the blocks start from the scene's coarse cut.
+    uint32_t* bin_count;
+    uint2* bin_list;
+    uint32_t ntri;              // triangles of the scene: no list entry is followed past the arrays
 };
 
 // How a frame's traced rectangle is worked through (chosen per frame by plan_tile_frame):
@@ -1120,10 +1260,12 @@ __device__ __forceinline__ void tile_block(const FrameK& f, const TilePlan& pl, 
         uint64_t dummy;
         if (!out_index(f, tx0, ty0, dummy)) return;
     }
+    uint32_t* const bin_count = pl.bin_count ? pl.bin_count + tb : nullptr;
+    const uint2* const bin_list = pl.bin_list + (size_t)tb * (uint32_t)kRangeCap;
     if constexpr (MODE == kBlocks)
-        trace_block(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+        trace_block(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, bin_count, bin_list, pl.ntri, pl.vec4, ao, out);
     else
-        trace_tile<4, MODE == kBatched>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, out);
+        trace_tile<4, MODE == kBatched>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, bin_count, bin_list, pl.ntri, pl.vec4, ao, out);
 }
 
 // One workgroup of the fill part: block `fb` of pl.fill_blocks.  The fill blocks store the clear values of every
@@ -1133,7 +1275,7 @@ __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, u
     const uint32_t tiles_x = pl.tiles_x, ntiles = pl.ntiles, fill_blocks = pl.fill_blocks;
     const uint32_t pixel_blocks = pl.pixel_blocks, row4_magic = pl.row4_magic;
     const int vec4 = pl.vec4;
-    if (f.flags & kDebugSkipFill) return;
+    if (INV_DBG(f, kDebugSkipFill)) return;
     const uint32_t edge = pl.block_px;
     const uint32_t hx0 = f.rx0 & ~(edge - 1u), hy0 = f.ry0 & ~(edge - 1u);
     const uint32_t hx1 = hx0 + tiles_x * edge, hy1 = hy0 + (tiles_x ? ntiles / tiles_x : 0u) * edge; // traced rectangle
@@ -1143,10 +1285,14 @@ __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, u
         // of kFillRun consecutive chunks; a run that lies in a row-major frame and touches no row of the traced
         // rectangle (most do) is stored with one address per attachment and immediate offsets, without any per-lane
         // pixel arithmetic.
-        // Write-through stores (sc1): the clear values leave the XCD's L2 as they are written instead of staying
-        // behind as dirty lines that push the scene out and are written back later (measured against plain and
-        // non-temporal stores: 12.8 -> 12.1 us per frame alone, 7.8 -> 6.8 us with two frames in flight).  The
-        // trailing s_nop keeps the next instruction off the data registers until the store has read them.
+        // Write-through, non-temporal stores (sc1 nt).  Write-through: the clear values leave the XCD's L2 as they
+        // are written instead of staying behind as dirty lines that push the scene out and are written back later
+        // (12.8 -> 12.1 us per frame alone, 7.8 -> 6.8 us with two frames in flight).  Non-temporal: they are not
+        // kept in the Infinity Cache either.  With sc1 alone a job whose attachment sets fit that cache (eight 1080p
+        // sets: 199 MB) clears a frame in 3.2 us and one whose sets do not in 4.25 us; with sc1 nt both take 3.8 us,
+        // and whole frames (clear and traced blocks) take no longer than the clear alone, 3.76 us = 6.8 TB/s into
+        // HBM, where sc1 alone took 4.6 us once the sets outgrew the cache.  The trailing s_nop keeps the next
+        // instruction off the data registers until the store has read them.
         const uint32_t row4 = (f.rowmajor ? f.w : f.tile) >> 2; // chunks per stored row
         const uint32_t nchunks = (uint32_t)(f.npix >> 2);          // the host keeps npix near 2^31 at most, so c0 + stride cannot wrap
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1156,9 +1302,12 @@ __device__ __forceinline__ void fill_part(const FrameK& f, const TilePlan& pl, u
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t wave0 = __builtin_amdgcn_readfirstlane(fb * 4u + (threadIdx.x >> 6));
         const uint32_t run_stride = fill_blocks * 4u * kFillRun;
-#define INV_FILL_ST(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory")
+#ifndef INV_FILL_MODS
+#define INV_FILL_MODS "sc1 nt"
+#endif
+#define INV_FILL_ST(v, p) asm volatile("global_store_dwordx4 %0, %1, off " INV_FILL_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory")
 #define INV_FILL_AT(v, p, off) \
-    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "n"(off) : "memory")
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " INV_FILL_MODS "\n\ts_nop 1" ::"v"(p), "v"(v), "n"(off) : "memory")
 #define INV_FILL_RUN(v, p)                                             \
     do {                                                               \
         INV_FILL_AT(v, p, 0);                                          \
@@ -1301,6 +1450,126 @@ __global__ __launch_bounds__(256, 4) void k_render_tile_batch(Batch b, const flo
         tile_block<kBlocks>(b.fr[i].f, b.fr[i].pl, local, S, TA, TB, TC, nodes, cut, cut_groups, ncut, ao, b.fr[i].out);
     else
         fill_part(b.fr[i].f, b.fr[i].pl, local - b.fr[i].pl.ntiles, b.fr[i].out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// binning pass: the fine cut's leaf ranges -> per-block lists, once per frame
+// ------------------------------------------------------------------------------------------------
+// One lane per record of the scene's fine cut (a subtree of at most kRangeMax leaves with its box).  The box, grown as
+// the tile kernel grows it, is carried to the framebuffer corner by corner with the frame's own matrices; the blocks
+// its pixel rectangle (widened by 1/8 pixel) touches get the record's leaf range appended to their lists.  A box lies
+// outside a block's frustum exactly when its projected rectangle misses the block, so the lists are what the blocks'
+// own frustum tests would have kept.  Why they are conservative: a triangle that passes the Moller-Trumbore test has
+// its hit point inside its own box grown by one guard pad, hence inside the subtree's box grown by two; that point
+// lies on the sample's ray and so projects to the sample position inside the pixel, to within the roundings of this
+// projection and of the ray's inverse matrix (about 10^-3 pixel at the largest extents the API accepts).  A box that
+// reaches the eye's plane is listed for every block.
+// Lists are appended to in scheduling order: the tile kernel's
+// result is a minimum over the candidates and does not depend on their order.  A list that is full keeps counting;
+// its block sees the count and falls back to the per-lane traversal.
+__device__ __forceinline__ bool bin_owned(const FrameK& f, const TilePlan& pl, uint32_t bx, uint32_t by) {
+    if (f.nranks <= 1) return true;
+    const uint32_t edge = pl.block_px;
+    uint64_t dummy;
+    return out_index(f, (f.rx0 & ~(edge - 1u)) + bx * edge, (f.ry0 & ~(edge - 1u)) + by * edge, dummy);
+}
+
+// `rpw` records per workgroup (a power of two, at most 256: 256 for scenes with hundreds of thousands of records,
+// fewer for small scenes, whose few thousand (record, block) pairs then spread over more workgroups).  The lanes first
+// find their records' block rectangles, a scan in LDS numbers the (record, block) pairs of the workgroup, and then
+// every lane takes pairs: no lane waits for one atomic after another on behalf of a record that touches many blocks,
+// and a lane's four pairs per step are in flight together.
+__global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __restrict__ fine, uint32_t nfine,
+                                                    uint32_t rpw) {
+    __shared__ uint4 s_rect[256];
+    __shared__ uint2 s_entry[256];
+    __shared__ uint32_t s_off[257]; // pairs before record r of this workgroup; [rpw] = all pairs
+    __shared__ uint32_t s_wave[4];
+    const FrameK& f = b.fr[blockIdx.y].f;
+    const TilePlan& pl = b.fr[blockIdx.y].pl;
+    if (!pl.bin_count || pl.ntiles == 0) return; // block-uniform
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * rpw + tid;
+    const uint32_t tiles_x = pl.tiles_x, tiles_y = pl.ntiles / pl.tiles_x;
+    uint32_t bx0 = 1, bx1 = 0, by0 = 1, by1 = 0; // empty
+    uint2 entry = make_uint2(0u, 0u);
+    if (tid < rpw && i < nfine) {
+        const float4 lo = fine[2 * (size_t)i], hi = fine[2 * (size_t)i + 1];
+        entry = make_uint2(__float_as_uint(lo.w), __float_as_uint(hi.w));
+        const float grow = 2.0f * f.pad;
+        const float cx[2] = {lo.x - grow, hi.x + grow}, cy[2] = {lo.y - grow, hi.y + grow}, cz[2] = {lo.z - grow, hi.z + grow};
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        bool whole = false;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float x = cx[c & 1], y = cy[(c >> 1) & 1], z = cz[c >> 2];
+            const float xv = (f.mv[0] * x + f.mv[1] * y) + (f.mv[2] * z + f.mv[3]);
+            const float yv = (f.mv[4] * x + f.mv[5] * y) + (f.mv[6] * z + f.mv[7]);
+            const float zv = (f.mv[8] * x + f.mv[9] * y) + (f.mv[10] * z + f.mv[11]);
+            const float w = -zv; // w_clip of a GLM perspective
+            const float rw = 1.0f / w;
+            const float fx = ((f.p00 * xv) * rw + 1.0f) * (0.5f * f.wf);
+            const float fy = ((f.p11 * yv) * rw + 1.0f) * (0.5f * f.hf);
+            whole = whole || !(w > 1e-30f) || !(fx == fx) || !(fy == fy);
+            xmin = fminf(xmin, fx), xmax = fmaxf(xmax, fx), ymin = fminf(ymin, fy), ymax = fmaxf(ymax, fy);
+        }
+        const float edge = (float)pl.block_px, redge = 1.0f / edge; // 8 or 16: exact
+        const float hx0 = (float)(f.rx0 & ~(pl.block_px - 1u)), hy0 = (float)(f.ry0 & ~(pl.block_px - 1u));
+        const float m = 0.125f;
+        float fx0 = floorf(((xmin - m) - hx0) * redge), fx1 = floorf(((xmax + m) - hx0) * redge);
+        float fy0 = floorf(((ymin - m) - hy0) * redge), fy1 = floorf(((ymax + m) - hy0) * redge);
+        if (whole) fx0 = 0.0f, fy0 = 0.0f, fx1 = (float)tiles_x, fy1 = (float)tiles_y;
+        if (fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= (float)(tiles_x - 1u) && fy0 <= (float)(tiles_y - 1u)) {
+            bx0 = (uint32_t)fmaxf(fx0, 0.0f), by0 = (uint32_t)fmaxf(fy0, 0.0f);
+            bx1 = (uint32_t)fminf(fx1, (float)(tiles_x - 1u)), by1 = (uint32_t)fminf(fy1, (float)(tiles_y - 1u));
+        }
+    }
+    const bool any = bx0 <= bx1 && by0 <= by1;
+    const uint32_t nb = any ? (bx1 - bx0 + 1u) * (by1 - by0 + 1u) : 0u;
+    // exclusive scan of nb over the workgroup's lanes
+    uint32_t incl = nb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    s_rect[tid] = make_uint4(bx0, by0, bx1, by1), s_entry[tid] = entry;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
+    s_off[tid] = before + incl - nb;
+    if (tid == 255u) s_off[256] = before + incl;
+    __syncthreads();
+    const uint32_t npairs = s_off[256];
+    for (uint32_t base = 0; base < npairs; base += 1024u) { // block-uniform
+        uint32_t bin[4], at[4];
+        uint2 e[4];
+        bool go[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = base + (uint32_t)u * 256u + tid;
+            go[u] = false, bin[u] = 0, at[u] = 0, e[u] = make_uint2(0u, 0u);
+            if (p < npairs) {
+                // the record this pair belongs to: the last r with s_off[r] <= p
+                uint32_t r = 0;
+#pragma unroll
+                for (uint32_t step = 128u; step != 0u; step >>= 1)
+                    if (s_off[r + step] <= p) r += step;
+                const uint4 rc = s_rect[r];
+                const uint32_t k = p - s_off[r], wx = rc.z - rc.x + 1u;
+                const uint32_t bx = rc.x + k % wx, by = rc.y + k / wx;
+                go[u] = bin_owned(f, pl, bx, by);
+                bin[u] = by * tiles_x + bx, e[u] = s_entry[r];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (go[u]) at[u] = atomicAdd(&pl.bin_count[bin[u]], 1u);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (go[u] && at[u] < (uint32_t)kRangeCap) pl.bin_list[(size_t)bin[u] * (uint32_t)kRangeCap + at[u]] = e[u];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1460,6 +1729,7 @@ __global__ __launch_bounds__(256) void k_ao_resolve(FrameK f, AoK ao, Outputs ou
 // Grid terms of one frame of the tile kernel and the way its traced rectangle is worked through.
 static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch, int* mode) {
     TilePlan pl;
+    pl.bin_count = nullptr, pl.bin_list = nullptr, pl.ntri = sc.ntri;
     if (f.rowmajor)
         pl.pixel_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
     else
@@ -1490,8 +1760,66 @@ static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Ou
     return pl;
 }
 
+// ---- the binning pass: when it runs, and where its bins live ----
+// INV_BINS=0 / 1 in the environment: never / whenever possible (measurements); otherwise scenes whose coarse cut is
+// capped (their blocks would walk the tree level by level from it) are binned, and small scenes are not: the pass is a
+// launch of its own, some five microseconds in front of draws that take four to ten, and what it saves their blocks
+// (one of three dependent round trips) is less than that (measured: 3.7 -> 4.4 us per frame for batches of the
+// 1080p bunny, 11 -> 16 us for a draw on its own; 0.67 -> 0.52 ms for the 5 M-triangle scene).
+static int bins_env() {
+    static const int v = [] {
+        const char* e = std::getenv("INV_BINS");
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    return v;
+}
+
+// Every corner of the scene's box (grown) in front of the eye: otherwise most boxes reach the eye's plane and would
+// be listed for every block.
+static bool eye_outside_scene(const FrameK& f, const DeviceScene& sc) {
+    const float grow = 4.0f * f.pad;
+    for (int c = 0; c < 8; c++) {
+        const float x = (c & 1) ? sc.bbox[3] + grow : sc.bbox[0] - grow, y = (c & 2) ? sc.bbox[4] + grow : sc.bbox[1] - grow;
+        const float z = (c & 4) ? sc.bbox[5] + grow : sc.bbox[2] - grow;
+        const float zv = (f.mv[8] * x + f.mv[9] * y) + (f.mv[10] * z + f.mv[11]);
+        if (!(-zv > 1e-6f * ((std::fabs(x) + std::fabs(y)) + (std::fabs(z) + 1.0f)))) return false;
+    }
+    return true;
+}
+
+static size_t bin_counts_bytes(uint64_t nbins) { return Arena::aligned((size_t)nbins * 4); }
+size_t bin_mem_bytes(uint64_t nbins) { return nbins ? bin_counts_bytes(nbins) + (size_t)nbins * kRangeCap * sizeof(uint2) : 0; }
+
+uint32_t tile_bins_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch) {
+    if (f.npix == 0 || !sc.has_bvh || sc.nfine == 0 || sc.height > (uint32_t)kStack) return 0;
+    if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE)) return 0;
+    const int env = bins_env();
+    (void)batch;
+    if (env == 0 || (env < 0 && sc.nfine <= kCutCap)) return 0;
+    if (!eye_outside_scene(f, sc)) return 0;
+    int mode = kBlocks;
+    const TilePlan pl = plan_tile_frame(f, sc, out, batch, &mode);
+    if (bin_mem_bytes(pl.ntiles) > ((size_t)1 << 30)) return 0; // a gigabyte of lists: start from the coarse cut instead
+    return pl.ntiles;
+}
+
+// Points the plan at bins [first, first + pl.ntiles) of `bins` (sized by the caller from tile_bins_wanted).
+static bool attach_bins(TilePlan& pl, const BinMem* bins, uint32_t first, uint32_t wanted) {
+    if (!bins || !bins->base || wanted == 0 || wanted != pl.ntiles || (uint64_t)first + wanted > bins->nbins) return false;
+    pl.bin_count = (uint32_t*)bins->base + first;
+    pl.bin_list = (uint2*)((char*)bins->base + bin_counts_bytes(bins->nbins)) + (size_t)first * kRangeCap;
+    return true;
+}
+
+static void launch_bin_ranges(hipStream_t s, const Batch& b, const DeviceScene& sc) {
+    // small scenes: fewer records per workgroup, so that their (record, block) pairs spread over many workgroups
+    const uint32_t rpw = sc.nfine > 65536u ? 256u : sc.nfine > 8192u ? 64u : 16u;
+    hipLaunchKernelGGL(k_bin_ranges, dim3((sc.nfine + rpw - 1u) / rpw, b.nframes), dim3(256), 0, s, b, (const float4*)sc.fine,
+                       sc.nfine, rpw);
+}
+
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao,
-                             const Outputs& out) {
+                             const Outputs& out, const BinMem* bins) {
     if (f.npix == 0) return hipSuccess;
     if (!sc.has_bvh || sc.height > (uint32_t)kStack) return launch_render_brute(s, f, sc, ao, out);
     if (f.flags & INV_LANE_TRAVERSAL) {
@@ -1507,8 +1835,14 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         return hipGetLastError();
     }
     int mode = kBlocks;
-    const TilePlan pl = plan_tile_frame(f, sc, out, false, &mode);
+    TilePlan pl = plan_tile_frame(f, sc, out, false, &mode);
     if (pl.ntiles + pl.fill_blocks == 0) return hipSuccess;
+    if (attach_bins(pl, bins, 0, tile_bins_wanted(f, sc, out, false))) {
+        Batch b;
+        std::memset(&b, 0, sizeof b);
+        b.nframes = 1, b.fr[0].f = f, b.fr[0].pl = pl, b.fr[0].out = out;
+        launch_bin_ranges(s, b, sc);
+    }
 #define INV_LAUNCH_TILE(MODE)                                                                                        \
     hipLaunchKernelGGL((k_render_tile<MODE>), dim3((MODE == kBatched ? xcd_run_grid(pl.ntiles) : pl.ntiles) + pl.fill_blocks), dim3(256), 0, s, f, pl, \
                        (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, \
@@ -1532,24 +1866,28 @@ bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out) 
 }
 
 hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
-                               const DeviceScene& sc) {
+                               const DeviceScene& sc, const BinMem* bins) {
     if (n == 0) return hipSuccess;
     if (n > kBatchMax) return hipErrorInvalidValue;
     Batch b;
     std::memset(&b, 0, sizeof b);
     b.nframes = n;
-    uint32_t blocks = 0;
+    uint32_t blocks = 0, first_bin = 0;
+    bool binned = false;
     for (uint32_t i = 0; i < n; i++) {
         int mode = kBlocks;
         b.fr[i].f = frames[i];
         b.fr[i].out = outs[i];
         b.fr[i].pl = plan_tile_frame(frames[i], sc, outs[i], true, &mode);
         if (mode != kBlocks) return hipErrorInvalidValue; // the caller asks tile_batchable first
+        const uint32_t wanted = tile_bins_wanted(frames[i], sc, outs[i], true);
+        if (attach_bins(b.fr[i].pl, bins, first_bin, wanted)) binned = true, first_bin += wanted;
         blocks += b.fr[i].pl.ntiles + b.fr[i].pl.fill_blocks;
         b.block_end[i] = blocks;
     }
     for (uint32_t i = n; i < kBatchMax; i++) b.block_end[i] = blocks;
     if (blocks == 0) return hipSuccess;
+    if (binned) launch_bin_ranges(s, b, sc); // one pass for all frames of the launch
     hipLaunchKernelGGL(k_render_tile_batch, dim3(blocks), dim3(256), 0, s, b, (const float4*)sc.triA,
                        (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, (const float4*)sc.cut,
                        (const float4*)sc.cut_groups, sc.ncut);

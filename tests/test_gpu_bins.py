@@ -1,0 +1,96 @@
+"""The per-frame binning pass: the scene's fine cut, and draws that start from their bins instead of the coarse cut.
+
+A draw gives the same pixels whether it is binned or not (the winner is a minimum over a superset of candidates), so
+every parity test applies to both; this file checks the fine cut itself, then runs the parity suite again in a process
+that bins every draw (INV_BINS=1: by default only frames that share a launch and scenes with a capped coarse cut are
+binned), and draws that mix binned and un-binned frames.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+import objfmt
+import renderer_amd as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check_fine_cut(scene, xyzw, idx):
+    """Every sorted leaf in exactly one record of at most 16 leaves, each box the union of its triangles' boxes."""
+    lo, hi, first, count = scene.read_fine_cut()
+    ntri = idx.size // 3
+    assert len(first) > 0 and count.min() >= 1 and count.max() <= 16
+    order = np.argsort(first, kind="stable")
+    f, c = first[order].astype(np.int64), count[order].astype(np.int64)
+    assert f[0] == 0 and np.array_equal(f[1:], (f + c)[:-1]) and f[-1] + c[-1] == ntri  # a partition of [0, ntri)
+    tri = xyzw[idx.reshape(-1, 3).astype(np.int64), :3]  # [ntri, 3 corners, xyz], primitive order
+    # the records' e1 = v1 - v0 is rounded once at assembly and the boxes are built from v0, v0 + e1, v0 + e2
+    v0 = tri[:, 0]
+    b1 = (v0 + (tri[:, 1] - v0).astype(np.float32)).astype(np.float32)
+    b2 = (v0 + (tri[:, 2] - v0).astype(np.float32)).astype(np.float32)
+    tlo, thi = np.minimum(v0, np.minimum(b1, b2)), np.maximum(v0, np.maximum(b1, b2))
+    sorted_prim = scene.read_lbvh()["order"].astype(np.int64)
+    tlo, thi = tlo[sorted_prim], thi[sorted_prim]
+    want_lo = np.minimum.reduceat(tlo, f, axis=0)
+    want_hi = np.maximum.reduceat(thi, f, axis=0)
+    assert np.array_equal(lo[order], want_lo) and np.array_equal(hi[order], want_hi)
+    return len(first)
+
+
+def test_fine_cut_of_the_bunny(bunny_path, bunny_mesh, gpu_ctx):
+    scene = R.Scene(gpu_ctx, R.Mesh.load_obj(bunny_path))
+    n = _check_fine_cut(scene, *bunny_mesh)
+    assert 4968 // 16 <= n <= 4968 // 4
+    scene.close()
+
+
+@pytest.mark.parametrize("ntri,seed", [(17, 1), (513, 2), (20000, 3)])
+def test_fine_cut_of_random_soups(gpu_ctx, ntri, seed):
+    xyz, faces = objfmt.random_soup(ntri, seed=seed, size=0.004)
+    if ntri > 100:
+        faces[ntri // 2:ntri // 2 + 40] = faces[:40]  # exact duplicates: equal keys, a run the index bits split
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    idx = faces.reshape(-1).astype(np.uint32)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    _check_fine_cut(scene, xyzw, idx)
+    scene.close()
+
+
+def test_tiny_scenes_have_no_fine_cut(gpu_ctx):
+    xyz, faces = objfmt.random_soup(16, seed=4, size=0.01)
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, faces.reshape(-1).astype(np.uint32)))
+    assert len(scene.read_fine_cut()[2]) == 0
+    scene.close()
+
+
+def test_fine_cut_of_the_large_instanced_scene(gpu_ctx, bunny_mesh):
+    xyzw, idx = bunny_mesh
+    tr = common.grid_translations(12)
+    fx, fi = common.flatten_instances(xyzw, idx, tr)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx), translations=tr)
+    n = _check_fine_cut(scene, fx, fi)
+    assert n > 2048  # more than the coarse cut holds: single draws of this scene are binned
+    scene.close()
+
+
+def test_parity_suite_with_every_draw_binned():
+    """The parity tests again with INV_BINS=1 (its own process: the library reads the variable once)."""
+    env = dict(os.environ, INV_BINS="1")
+    names = ("config1 or config2 or shading or jittered or samples_in or odd_extents or moved_camera or soup or tiny or "
+             "sharding or sparse_composite or turntable or in_flight or batched_draws or overflow or camera_inside or "
+             "ambient or instanced or ray_along or 8k")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_configs.py"), "-x", "-q", "-m", "gpu", "-k", names,
+                        "--timeout", "300", "--timeout-method", "thread", "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail

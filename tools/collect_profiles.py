@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--prefix", default="r01_final")
+    ap.add_argument("--prefix", default="r02_final")
     ap.add_argument("--frames-per-launch", type=int, default=4)
     a = ap.parse_args()
     src, dst = os.path.join(ROOT, "gpurun_out", a.tag), os.path.join(ROOT, "profiles")
@@ -38,6 +38,9 @@ def main():
     subprocess.check_call([sys.executable, tool, a.prefix, os.path.join(src, "stats"), "--fetch", os.path.join(src, "fetch"),
                            "--write", os.path.join(src, "write"), "--frames-per-launch", str(a.frames_per_launch)])
     subprocess.check_call([sys.executable, tool, a.prefix + "_ao64", os.path.join(src, "stats_ao")])
+    if os.path.exists(os.path.join(src, "pmc_cache.txt")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "valu_summary.py"), os.path.join(src, "pmc_cache.txt"),
+                               os.path.join(dst, a.prefix + "_valu.json")], stdout=subprocess.DEVNULL)
     shutil.rmtree(os.path.join(dst, "__pycache__"), ignore_errors=True)
 
 

@@ -11,6 +11,9 @@ import argparse
 import os
 
 os.environ["INV_TIMING_SWITCHES"] = "1"  # the library refuses the switches otherwise
+# the switches exist only in the timing build of the library (make -C renderer_amd/csrc timing)
+os.environ.setdefault("INVERT_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                     "renderer_amd", "libinvert_hip_timing.so"))
 import statistics
 import sys
 

@@ -7,7 +7,7 @@ for wl in bunny_1080p_primary_lambert_invert bunny_1080p_ao64; do
     for pass in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
         d="gpurun_out/pmc_cache/${wl}_$(echo $pass | cut -d' ' -f1)"
         rm -rf "$d"
-        timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$d" -- python3 bench.py --no-cpu-baseline --no-extra-passes --steps 1 --warmup 1 --frames-per-step 24 --workload $wl > /dev/null 2>&1
+        timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$d" -- python3 bench.py --no-cpu-baseline --no-extra-passes --steps 1 --warmup 1 --warmup-ms 0 --frames-per-step 24 --workload $wl > /dev/null 2>&1
     done
 done
 for wl in bunny_1080p_primary_lambert_invert bunny_1080p_ao64; do

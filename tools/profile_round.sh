@@ -3,12 +3,12 @@
 # passes, phase timing, per-tile statistics and the instruction-mix table.  Run on the GPU box from the repo root:
 #     bash tools/profile_round.sh TAG
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 rm -rf "$O" && mkdir -p "$O"
 export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 60 --warmup 6"
+B="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 60 --warmup 6 --warmup-ms 0"
 timeout -k 10 200 python3 bench.py > "$O/bench_default.json"
 timeout -k 10 200 python3 bench.py --workload bunny_4k_16spp > "$O/bench_4k_16spp.json"
 timeout -k 10 200 python3 bench.py --workload bunny_1080p_ao64 > "$O/bench_ao64.json"
