@@ -146,10 +146,11 @@ int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uin
                         uint32_t* leaf_parent, float* box);
 
 /* The scene's fine cut, which the per-frame binning pass reads instead of walking the tree: every subtree (or single
- * leaf) of at most 16 sorted leaves whose parent covers more, as 8 floats per record: box lo.xyz, first sorted leaf
+ * leaf) of at most INV_FINE_CUT_LEAVES sorted leaves whose parent covers more, as 8 floats per record: box lo.xyz, first sorted leaf
  * (uint32 bits), box hi.xyz, leaf count (uint32 bits); in no particular order.  *nrecords is the number of records
- * the scene holds (0: none -- fewer than 17 triangles, or a tree too unbalanced for the array); at most `cap` are
+ * the scene holds (0: none -- no more than INV_FINE_CUT_LEAVES triangles, or a tree too unbalanced for the array); at most `cap` are
  * copied.  `records` may be NULL. */
+#define INV_FINE_CUT_LEAVES 16u
 int inv_scene_read_fine_cut(inv_scene* scene, float* records, uint32_t cap, uint32_t* nrecords);
 
 /* ---- the vertex stage on its own ---------------------------------------------------------------------------- */

@@ -559,6 +559,7 @@ int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uin
     return INV_OK;
 }
 
+static_assert(INV_FINE_CUT_LEAVES == kFineMax, "the header documents the fine cut's record size");
 int inv_scene_read_fine_cut(inv_scene* scene, float* records, uint32_t cap, uint32_t* nrecords) {
     if (!scene || !nrecords) return fail(INV_ERR_ARG, "inv_scene_read_fine_cut: null argument");
     const DeviceScene& d = scene->d;

@@ -38,6 +38,15 @@ void hit_rect(const FrameK& f, const float bbox[6], uint32_t rect[4]);
 // Start set of the tile kernel: at most kCutCap subtrees (or single leaves) that together cover the scene, each
 // with its box; subtrees of at most kRangeMax leaves are taken whole as a range of the sorted triangle array.
 constexpr uint32_t kCutCap = 2048, kRangeMax = 16, kCutGroup = 16;
+// Leaves per record of the fine cut (a power of two, at most kRangeMax).  Smaller records have tighter boxes, so a
+// block is handed fewer triangles that cannot touch it, but there are more of them for the binning pass to place and
+// a block's list (256 ranges) holds fewer triangles: with 4 leaves the tiles of the 5 M-triangle scene (some 700
+// triangles each) overflowed their lists and the frame took 3.7 ms instead of 0.52 ms with 16.
+#ifndef INV_FINE_MAX
+#define INV_FINE_MAX 16
+#endif
+constexpr uint32_t kFineMax = INV_FINE_MAX;
+static_assert(kFineMax <= kRangeMax && (kFineMax & (kFineMax - 1u)) == 0u, "a power of two, at most kRangeMax");
 
 // One device allocation handed out in 256-byte aligned pieces (a scene build makes two: what the scene keeps and
 // what only the build needs).
@@ -71,7 +80,7 @@ struct DeviceScene {
     float* cut = nullptr;          // kCutCap records of 8 floats: lo xyz, first leaf | node, hi xyz, leaf count
     float* cut_groups = nullptr;   // boxes of kCutGroup consecutive cut records: 8 floats each
     uint32_t ncut = 0;             // records in use
-    float* fine = nullptr;         // the fine cut: every subtree of at most kRangeMax leaves under a larger parent,
+    float* fine = nullptr;         // the fine cut: every subtree of at most kFineMax leaves under a larger parent,
                                    // 8 floats per record (lo xyz, first leaf, hi xyz, leaf count), in no particular order
     uint32_t nfine = 0;            // records of the fine cut; 0: the scene has none (a few triangles, or too unbalanced)
     bool has_bvh = false;

@@ -408,7 +408,7 @@ __device__ __forceinline__ void block_append(bool flag, uint32_t value, uint32_t
     __syncthreads(); // the next call overwrites s_wave
 }
 
-// The fine cut: every subtree (or single leaf) of at most kRangeMax leaves whose parent covers more.  These subtrees
+// The fine cut: every subtree (or single leaf) of at most kFineMax leaves whose parent covers more.  These subtrees
 // hold every leaf exactly once; a record is 8 floats, (lo.xyz, first sorted leaf) (hi.xyz, leaf count), the box being
 // the child box the parent's node record carries.  The per-frame binning pass reads them instead of walking the tree.
 // A finished node emits the records of its small children; one counter update per workgroup (see block_append), so
@@ -421,8 +421,8 @@ __device__ __forceinline__ void emit_fine(bool finished, uint32_t c0, uint2 leav
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t gamma = c0 & 0x7FFFFFFFu;
     const uint32_t n0 = gamma - leaves.x + 1u, n1 = leaves.y - gamma;
-    const bool big = finished && leaves.y - leaves.x + 1u > kRangeMax;
-    const bool f0 = big && n0 <= kRangeMax, f1 = big && n1 <= kRangeMax;
+    const bool big = finished && leaves.y - leaves.x + 1u > kFineMax;
+    const bool f0 = big && n0 <= kFineMax, f1 = big && n1 <= kFineMax;
     const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
     if (lane == 0) s_wave[wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
     __syncthreads();
@@ -753,10 +753,10 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
 
 } // namespace
 
-// Records the fine cut may hold.  A tree over well spread keys has about n / 10 subtrees of at most kRangeMax leaves
-// under larger parents; badly unbalanced trees have up to n.  A build that needs more than this leaves the scene
-// without a fine cut (its draws then start from the coarse cut, as scenes of a few triangles do).
-static uint32_t fine_cap_for(uint32_t n) { return n / 4u + 1024u; }
+// Records the fine cut may hold.  A tree over well spread keys has about 1.6 n / kFineMax subtrees of at most kFineMax
+// leaves under larger parents; badly unbalanced trees have up to n.  A build that needs more than this leaves the
+// scene without a fine cut (its draws then start from the coarse cut, as scenes of a few triangles do).
+static uint32_t fine_cap_for(uint32_t n) { return (uint32_t)std::min<uint64_t>(n, (uint64_t)n * 5u / (2u * kFineMax) + 1024u); }
 static uint32_t bounds_blocks_for(uint32_t n) { return std::min<uint32_t>((n + 255) / 256, 1024); }
 static uint32_t sort_tiles_for(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 

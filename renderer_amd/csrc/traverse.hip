@@ -586,6 +586,9 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     if (tid < 256) S.srgb[tid] = srgb_entry;
     // ---- phase 2: one candidate triangle per lane against the tile's frustum and facing ----
     const uint32_t nranges = S.n_ranges;
+    // lanes per range: a bin's ranges are records of the fine cut (at most kFineMax leaves), the coarse cut's have up
+    // to kRangeMax
+    const uint32_t rshift = bin_count ? (uint32_t)__builtin_ctz(kFineMax) : (uint32_t)__builtin_ctz(kRangeMax);
     // the triangles of ranges [r0, r1) that can cover a sample of the tile -> S.u.t.rec (arguments block-uniform)
     const auto build_records = [&](uint32_t r0, uint32_t r1) {
         // directions through the four corners of the grown tile (for the facing test)
@@ -601,7 +604,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
 #pragma unroll
         for (int c = 0; c < 4; c++) dabs = fmaxf(dabs, fmaxf(fmaxf(fabsf(cdx[c]), fabsf(cdy[c])), fabsf(cdz[c])));
         dabs = dabs + dabs;
-        const uint32_t nslots = (r1 - r0) * kRangeMax;
+        const uint32_t nslots = (r1 - r0) << rshift;
         for (uint32_t base = 0; base < nslots; base += 2u * NT) { // block-uniform trip count; two triangles per lane
             float4 A2[2], B2[2], C2[2];                           // and trip, all loads in flight before the first test
             uint32_t k2[2] = {0, 0};
@@ -611,8 +614,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                 const uint32_t q = base + (uint32_t)u * NT + tid;
                 have[u] = false;
                 if (q < nslots) {
-                    const uint2 rg = S.u.t.ranges[r0 + q / kRangeMax];
-                    const uint32_t off = q % kRangeMax;
+                    const uint2 rg = S.u.t.ranges[r0 + (q >> rshift)];
+                    const uint32_t off = q & ((1u << rshift) - 1u);
                     if (off < rg.y && rg.x + off < ntri) { // (the second test never fails for a list built from this scene)
                         k2[u] = rg.x + off;
                         have[u] = true, A2[u] = TA[k2[u]], B2[u] = TB[k2[u]], C2[u] = TC[k2[u]];
@@ -690,7 +693,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     //      records for every batch; the winner is then named by its position in the sorted triangle arrays
     //      instead of its LDS slot. ----
     constexpr bool batched = BATCHED;
-    constexpr uint32_t kBatchRanges = kTileCap / kRangeMax;
+    const uint32_t kBatchRanges = (uint32_t)kTileCap >> rshift; // ranges whose triangles always fit the record list
     const uint32_t nbatches = batched ? (nranges + kBatchRanges - 1u) / kBatchRanges : 1u;
     const uint32_t pix = py * f.w + px;
     float sr = 0.0f, sg = 0.0f, sb = 0.0f; // first wave only
@@ -1048,7 +1051,10 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
 #pragma unroll
         for (int c = 0; c < 4; c++) dabs = fmaxf(dabs, fmaxf(fmaxf(fabsf(cdx[c]), fabsf(cdy[c])), fabsf(cdz[c])));
         dabs = dabs + dabs;
-        const uint32_t nslots = nranges * kRangeMax;
+        // lanes per range: a bin's ranges are records of the fine cut (at most kFineMax leaves), the coarse cut's
+        // have up to kRangeMax
+        const uint32_t rshift = bin_count ? (uint32_t)__builtin_ctz(kFineMax) : (uint32_t)__builtin_ctz(kRangeMax);
+        const uint32_t nslots = nranges << rshift;
         for (uint32_t base = 0; base < nslots; base += 2u * NT) { // block-uniform trip count; two triangles per lane
             float4 A[2], B[2], C[2];                              // and trip, all loads in flight before the first test
             bool have[2];
@@ -1057,8 +1063,8 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
                 const uint32_t q = base + (uint32_t)u * NT + tid;
                 have[u] = false;
                 if (q < nslots) {
-                    const uint2 rg = S.u.t.ranges[q / kRangeMax];
-                    const uint32_t off = q % kRangeMax;
+                    const uint2 rg = S.u.t.ranges[q >> rshift];
+                    const uint32_t off = q & ((1u << rshift) - 1u);
                     if (off < rg.y && rg.x + off < ntri) { // (the second test never fails for a list built from this scene)
                         const uint32_t k = rg.x + off;
                         have[u] = true, A[u] = TA[k], B[u] = TB[k], C[u] = TC[k];
@@ -1455,7 +1461,7 @@ __global__ __launch_bounds__(256, 4) void k_render_tile_batch(Batch b, const flo
 // ------------------------------------------------------------------------------------------------
 // binning pass: the fine cut's leaf ranges -> per-block lists, once per frame
 // ------------------------------------------------------------------------------------------------
-// One lane per record of the scene's fine cut (a subtree of at most kRangeMax leaves with its box).  The box, grown as
+// One lane per record of the scene's fine cut (a subtree of at most kFineMax leaves with its box).  The box, grown as
 // the tile kernel grows it, is carried to the framebuffer corner by corner with the frame's own matrices; the blocks
 // its pixel rectangle (widened by 1/8 pixel) touches get the record's leaf range appended to their lists.  A box lies
 // outside a block's frustum exactly when its projected rectangle misses the block, so the lists are what the blocks'
@@ -1795,7 +1801,7 @@ uint32_t tile_bins_wanted(const FrameK& f, const DeviceScene& sc, const Outputs&
     if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE)) return 0;
     const int env = bins_env();
     (void)batch;
-    if (env == 0 || (env < 0 && sc.nfine <= kCutCap)) return 0;
+    if (env == 0 || (env < 0 && sc.ntri <= kCutCap * 8u)) return 0; // (a cut of 2048 subtrees of 8 leaves is not capped)
     if (!eye_outside_scene(f, sc)) return 0;
     int mode = kBlocks;
     const TilePlan pl = plan_tile_frame(f, sc, out, batch, &mode);

@@ -18,13 +18,14 @@ import renderer_amd as R
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FINE = 16  # INV_FINE_CUT_LEAVES
 
 
 def _check_fine_cut(scene, xyzw, idx):
-    """Every sorted leaf in exactly one record of at most 16 leaves, each box the union of its triangles' boxes."""
+    """Every sorted leaf in exactly one record of at most FINE leaves, each box the union of its triangles' boxes."""
     lo, hi, first, count = scene.read_fine_cut()
     ntri = idx.size // 3
-    assert len(first) > 0 and count.min() >= 1 and count.max() <= 16
+    assert len(first) > 0 and count.min() >= 1 and count.max() <= FINE
     order = np.argsort(first, kind="stable")
     f, c = first[order].astype(np.int64), count[order].astype(np.int64)
     assert f[0] == 0 and np.array_equal(f[1:], (f + c)[:-1]) and f[-1] + c[-1] == ntri  # a partition of [0, ntri)
@@ -45,7 +46,7 @@ def _check_fine_cut(scene, xyzw, idx):
 def test_fine_cut_of_the_bunny(bunny_path, bunny_mesh, gpu_ctx):
     scene = R.Scene(gpu_ctx, R.Mesh.load_obj(bunny_path))
     n = _check_fine_cut(scene, *bunny_mesh)
-    assert 4968 // 16 <= n <= 4968 // 4
+    assert 4968 // FINE <= n <= 4968
     scene.close()
 
 
@@ -63,7 +64,7 @@ def test_fine_cut_of_random_soups(gpu_ctx, ntri, seed):
 
 
 def test_tiny_scenes_have_no_fine_cut(gpu_ctx):
-    xyz, faces = objfmt.random_soup(16, seed=4, size=0.01)
+    xyz, faces = objfmt.random_soup(FINE, seed=4, size=0.01)
     xyzw = np.zeros((len(xyz), 4), np.float32)
     xyzw[:, :3] = xyz
     scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, faces.reshape(-1).astype(np.uint32)))
