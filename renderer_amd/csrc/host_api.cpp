@@ -92,6 +92,8 @@ struct FrameScratch {
     float* ao_queue = nullptr; // occlusion-pass queue (grow-only): 256-byte header with the counter, then records
     uint64_t ao_cap = 0;
     BinMem bins; // bins of the binning pass (grow-only)
+    unsigned long long* vis = nullptr; // visibility buffer of frames drawn one lane per triangle (grow-only)
+    uint64_t vis_elems = 0;
 };
 
 struct inv_scene {
@@ -116,7 +118,7 @@ void dfree(T*& p) {
 void free_device_scene(DeviceScene& d) {
     dfree(d.arena); // every array of the scene lives in this one allocation
     d.xyzw = nullptr, d.idx = nullptr, d.triA = d.triB = d.triC = nullptr;
-    d.morton = nullptr, d.order = d.child = d.parent = d.leaf_parent = nullptr, d.nodes = d.cut = d.cut_groups = d.fine = nullptr;
+    d.morton = nullptr, d.order = d.child = d.parent = d.leaf_parent = nullptr, d.nodes = d.cut = d.cut_groups = d.fine = nullptr, d.slot_of = nullptr;
 }
 
 void free_frame_scratch(FrameScratch& fs) {
@@ -126,6 +128,8 @@ void free_frame_scratch(FrameScratch& fs) {
     fs.ao_cap = 0;
     dfree(fs.bins.base);
     fs.bins.nbins = 0;
+    dfree(fs.vis);
+    fs.vis_elems = 0;
 }
 
 // Tile sharding terms of a frame (one rank: row-major, several: tile slots).
@@ -645,6 +649,19 @@ int ensure_bins(hipStream_t stream, FrameScratch& fs, uint64_t nbins) {
     return INV_OK;
 }
 
+// A visibility buffer of at least `elems` entries in the scratch of a stream (grow-only); new memory is set to the
+// miss key once, after that the kernels leave every entry they touch at the miss key again.
+int ensure_vis(hipStream_t stream, FrameScratch& fs, uint64_t elems) {
+    if (elems <= fs.vis_elems) return INV_OK;
+    HIP_TRY(hipStreamSynchronize(stream)); // an earlier draw may still use the old buffer
+    dfree(fs.vis);
+    fs.vis_elems = 0;
+    HIP_TRY(hipMalloc((void**)&fs.vis, elems * 8));
+    fs.vis_elems = elems;
+    HIP_TRY(launch_vis_fill(stream, fs.vis, elems));
+    return INV_OK;
+}
+
 // With `noalloc` the draw takes its occlusion queue from the context's copy of `scratch` and refuses whatever would
 // need an allocation (host attachments, more queued pixels than the array holds).
 int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_camera* cam, const inv_params* params,
@@ -714,9 +731,11 @@ int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_
         HIP_TRY(launch_render_brute(stream, f, scene->d, ao, dev));
     } else {
         // (the entry point that allocates nothing draws from the coarse cut: same pixels, no bins)
-        const uint32_t nbins = noalloc ? 0u : tile_bins_wanted(f, scene->d, dev, false);
+        const bool scatter = !noalloc && scatter_wanted(f, scene->d, dev);
+        const uint32_t nbins = noalloc || scatter ? 0u : tile_bins_wanted(f, scene->d, dev, false);
         if (nbins && (rc = ensure_bins(stream, fs, nbins)) != INV_OK) return rc;
-        HIP_TRY(launch_render_bvh(stream, f, scene->d, ao, dev, nbins ? &fs.bins : nullptr));
+        if (scatter && (rc = ensure_vis(stream, fs, (uint64_t)f.w * f.h)) != INV_OK) return rc;
+        HIP_TRY(launch_render_bvh(stream, f, scene->d, ao, dev, nbins ? &fs.bins : nullptr, scatter ? fs.vis : nullptr));
     }
     HIP_TRY(launch_ao(stream, f, scene->d, ao, dev));
     if (!out->on_device) {

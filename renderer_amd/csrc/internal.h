@@ -76,6 +76,7 @@ struct DeviceScene {
     uint32_t* child = nullptr;     // 2*(ntri-1)
     uint32_t* parent = nullptr;    // ntri-1
     uint32_t* leaf_parent = nullptr; // ntri
+    uint32_t* slot_of = nullptr;   // ntri: primitive id -> storage slot (the inverse of `order`)
     float* nodes = nullptr;        // 16 floats per internal node: two child boxes, two child refs, leaf range
     float* cut = nullptr;          // kCutCap records of 8 floats: lo xyz, first leaf | node, hi xyz, leaf count
     float* cut_groups = nullptr;   // boxes of kCutGroup consecutive cut records: 8 floats each
@@ -107,8 +108,13 @@ size_t bin_mem_bytes(uint64_t nbins);
 // frame shares a launch with others.
 uint32_t tile_bins_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch);
 // `bins` may be null or too small: the draw then starts from the coarse cut (same pixels either way).
+// `vis`: a visibility buffer of width * height 64-bit entries, all equal to the miss key (launch_vis_fill; the
+// kernels leave it that way), for frames drawn one lane per triangle (scatter_wanted); null: such frames go through
+// the tile kernel like any other.
+bool scatter_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out);
+hipError_t launch_vis_fill(hipStream_t s, unsigned long long* vis, uint64_t n);
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out,
-                             const BinMem* bins);
+                             const BinMem* bins, unsigned long long* vis);
 // Several frames of one scene in one launch of the tile kernel (at most INV_BATCH_MAX; every frame must be
 // tile_batchable: LBVH scene, default traversal, not the dense variant; no occlusion pass).
 #define INV_BATCH_MAX 8

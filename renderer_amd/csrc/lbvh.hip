@@ -408,6 +408,13 @@ __device__ __forceinline__ void block_append(bool flag, uint32_t value, uint32_t
     __syncthreads(); // the next call overwrites s_wave
 }
 
+// primitive id -> storage slot, for kernels that know a pixel's winner by its primitive id only
+__global__ __launch_bounds__(256) void k_invert_order(const uint32_t* __restrict__ order, uint32_t n,
+                                                      uint32_t* __restrict__ slot_of) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < n) slot_of[order[k]] = k;
+}
+
 // The fine cut: every subtree (or single leaf) of at most kFineMax leaves whose parent covers more.  These subtrees
 // hold every leaf exactly once; a record is 8 floats, (lo.xyz, first sorted leaf) (hi.xyz, leaf count), the box being
 // the child box the parent's node record carries.  The per-frame binning pass reads them instead of walking the tree.
@@ -764,7 +771,7 @@ size_t lbvh_keep_bytes(uint32_t n) {
     if (n < 2) return 0;
     const size_t sizes[] = {(size_t)n * 8, (size_t)n * 4, (size_t)(n - 1) * 8, (size_t)(n - 1) * 4, (size_t)n * 4,
                             (size_t)(n - 1) * 64, (size_t)kCutCap * 32, (size_t)(kCutCap / kCutGroup) * 32,
-                            (size_t)fine_cap_for(n) * 32};
+                            (size_t)fine_cap_for(n) * 32, (size_t)n * 4};
     size_t total = 0;
     for (size_t b : sizes) total += Arena::aligned(b);
     return total;
@@ -811,7 +818,8 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     const uint32_t fine_cap = fine_cap_for(n);
     sc.fine = keep.take<float>((size_t)fine_cap * 32);
     sc.nfine = 0;
-    if (!range || !sc.cut_groups || !sc.fine) return hipErrorOutOfMemory; // the arenas were sized for something else
+    sc.slot_of = keep.take<uint32_t>((size_t)n * 4);
+    if (!range || !sc.cut_groups || !sc.fine || !sc.slot_of) return hipErrorOutOfMemory; // the arenas were sized for something else
     float4 *A1 = (float4*)sc.triA, *B1 = (float4*)sc.triB, *C1 = (float4*)sc.triC;
 
     const float4* T0 = (const float4*)records;
@@ -841,6 +849,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
         std::swap(vin, vout);
     }
     hipLaunchKernelGGL(k_permute, dim3(xcd_grid((n + 255) / 256)), blk, 0, s, T0, sc.order, n, A1, B1, C1);
+    hipLaunchKernelGGL(k_invert_order, grid_n, blk, 0, s, (const uint32_t*)sc.order, n, sc.slot_of);
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));

@@ -1579,6 +1579,129 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// triangles much smaller than a pixel: one lane per triangle instead of lists per tile
+// ------------------------------------------------------------------------------------------------
+// Where an 8x8 tile meets hundreds of triangles (the 32 x 32 grid of bunnies: 700 per covered tile, eleven per
+// pixel) the tile kernel spends its time building and testing lists of candidates that mostly miss.  Such frames
+// are drawn the other way round: every triangle finds the few pixel centres its own box can contain, runs the
+// Moller-Trumbore test of exactly those pixels' rays (same function, same operands, so the same bits as any other
+// kernel computes) and offers its (depth, primitive) key to the pixel's entry of a visibility buffer with a 64-bit
+// atomic minimum: the depth test LESS with the lower primitive winning ties (src/invert.cpp:1384 + draw order), and
+// independent of the order in which triangles arrive.  A second pass reads each pixel's winner, looks up where that
+// primitive sits in the sorted arrays, repeats the test once for the barycentric terms, shades and stores, and puts
+// the entry back to the miss key for the next frame.
+// Which pixels a triangle must try: a triangle that passes the test at a pixel has its hit point inside its own box
+// grown by one guard pad, and that point projects to the pixel centre (to within the roundings of this projection and
+// of the ray's inverse matrix: about 10^-3 pixel at the largest extents the API accepts); so the centre lies in the
+// rectangle that the eight corners of the box, grown by two pads, project to, widened by 1/8 pixel.  A box that
+// reaches the eye's plane tries every pixel of the frame's hit rectangle.
+// One sample per pixel only (frames with more take the tile kernel).
+__global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float4* __restrict__ TA,
+                                                           const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                                           uint32_t ntri, unsigned long long* __restrict__ vis) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= ntri) return;
+    const float4 A = TA[k], B = TB[k], C = TC[k];
+    // the triangle's box exactly as the guard of mt_test forms it
+    const float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
+    const float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
+    const float grow = 2.0f * f.pad;
+    const float X[2] = {fminf(A.x, fminf(bx, cx)) - grow, fmaxf(A.x, fmaxf(bx, cx)) + grow};
+    const float Y[2] = {fminf(A.y, fminf(by, cy)) - grow, fmaxf(A.y, fmaxf(by, cy)) + grow};
+    const float Z[2] = {fminf(A.z, fminf(bz, cz)) - grow, fmaxf(A.z, fmaxf(bz, cz)) + grow};
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    bool whole = false;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float x = X[c & 1], y = Y[(c >> 1) & 1], z = Z[c >> 2];
+        const float xv = (f.mv[0] * x + f.mv[1] * y) + (f.mv[2] * z + f.mv[3]);
+        const float yv = (f.mv[4] * x + f.mv[5] * y) + (f.mv[6] * z + f.mv[7]);
+        const float zv = (f.mv[8] * x + f.mv[9] * y) + (f.mv[10] * z + f.mv[11]);
+        const float w = -zv; // w_clip of a GLM perspective
+        const float rw = 1.0f / w;
+        const float fx = ((f.p00 * xv) * rw + 1.0f) * (0.5f * f.wf);
+        const float fy = ((f.p11 * yv) * rw + 1.0f) * (0.5f * f.hf);
+        whole = whole || !(w > 1e-30f) || !(fx == fx) || !(fy == fy);
+        xmin = fminf(xmin, fx), xmax = fmaxf(xmax, fx), ymin = fminf(ymin, fy), ymax = fmaxf(ymax, fy);
+    }
+    // pixel centres px + 0.5 inside [xmin - m, xmax + m], clipped to the rectangle that can contain hits
+    const float m = 0.125f;
+    float fx0 = ceilf(xmin - m - 0.5f), fx1 = floorf(xmax + m - 0.5f);
+    float fy0 = ceilf(ymin - m - 0.5f), fy1 = floorf(ymax + m - 0.5f);
+    if (whole) fx0 = 0.0f, fy0 = 0.0f, fx1 = f.wf, fy1 = f.hf;
+    if (!(fx1 >= (float)f.rx0 && fy1 >= (float)f.ry0 && fx0 <= (float)f.rx1 - 1.0f && fy0 <= (float)f.ry1 - 1.0f)) return;
+    const uint32_t x0 = (uint32_t)fmaxf(fx0, (float)f.rx0), y0 = (uint32_t)fmaxf(fy0, (float)f.ry0);
+    const uint32_t x1 = (uint32_t)fminf(fx1, (float)f.rx1 - 1.0f), y1 = (uint32_t)fminf(fy1, (float)f.ry1 - 1.0f);
+    if (x0 > x1 || y0 > y1) return;
+    // cull BACK (src/invert.cpp:1334): det = e1 . (d x e2) is linear in d and every ray direction of the rectangle is
+    // a convex combination of the directions through its corners; clearly negative at all four: no pixel can pass
+    {
+        const float nx = C.y * B.z - C.z * B.y, ny = C.z * B.x - C.x * B.z, nz = C.x * B.y - C.y * B.x;
+        float dmax = -INFINITY, scale = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float dx, dy, dz;
+            dir_at(f, (c & 1) ? (float)x1 + 1.0f + m : (float)x0 - m, (c & 2) ? (float)y1 + 1.0f + m : (float)y0 - m, dx, dy, dz);
+            dmax = fmaxf(dmax, (dx * nx + dy * ny) + dz * nz);
+            scale = fmaxf(scale, (fabsf(dx * nx) + fabsf(dy * ny)) + fabsf(dz * nz));
+        }
+        if (dmax < -1e-4f * scale) return;
+    }
+    for (uint32_t py = y0; py <= y1; py++)
+        for (uint32_t px = x0; px <= x1; px++) {
+            if (f.nranks > 1) { // another rank's tile
+                uint64_t dummy;
+                if (!out_index(f, px, py, dummy)) continue;
+            }
+            const Ray ray = make_ray(f, px, py, 0.5f, 0.5f);
+            Hit best = miss_hit();
+            mt_test(f, ray, A, B, C, k, best);
+            if (best.key != kMissKey) atomicMin(&vis[(size_t)py * f.w + px], (unsigned long long)best.key);
+        }
+}
+
+// One lane per output pixel: the winner of the pixel's visibility entry is shaded and stored, and the entry is put
+// back to the miss key.  `slot_of`: primitive id -> position in the sorted triangle arrays.
+__global__ __launch_bounds__(256) void k_scatter_resolve(FrameK f, const float4* __restrict__ TA,
+                                                         const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                                         const uint32_t* __restrict__ slot_of, uint32_t ntri,
+                                                         unsigned long long* __restrict__ vis, AoK ao, Outputs out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < f.npix;
+    uint32_t px = 0, py = 0;
+    if (live) live = work_to_pixel(f, i, px, py);
+    // (every lane of the wave goes through finish_pixel together: it ranks the lanes that queue occlusion records)
+    const uint32_t pix = py * f.w + px;
+    const Ray ray0 = make_ray(f, px, py, 0.5f, 0.5f);
+    Hit first = miss_hit();
+    float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
+    float4 Bw = make_float4(0.0f, 0.0f, 0.0f, 0.0f), Cw = Bw;
+    if (live) {
+        const unsigned long long key = vis[pix];
+        if (key != kMissKey) vis[pix] = kMissKey;
+        if (key != kMissKey && (uint32_t)key < ntri) { // (the second test never fails for keys the first pass wrote)
+            const uint32_t slot = slot_of[(uint32_t)key];
+            const float4 A = TA[slot];
+            Bw = TB[slot], Cw = TC[slot];
+            mt_test(f, ray0, A, Bw, Cw, slot, first); // the same test again: the same key, now with its terms
+            if (first.key != kMissKey) shade_hit(f, first, A, Bw, Cw, r, g, b);
+        }
+    }
+    if (ao.rays) {
+        // finish_pixel queues hit pixels with a wave-wide ranking: lanes without a pixel take part with a miss
+        Outputs o = out;
+        if (!live) o.color = nullptr, o.depth = nullptr, o.primid = nullptr;
+        finish_pixel(f, ao, o, i, pix, ray0, first, Bw, Cw, r, g, b);
+        return;
+    }
+    if (live) finish_pixel(f, ao, out, i, pix, ray0, first, Bw, Cw, r, g, b);
+}
+
+__global__ __launch_bounds__(256) void k_vis_fill(unsigned long long* __restrict__ vis, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) vis[i] = kMissKey;
+}
+
+// ------------------------------------------------------------------------------------------------
 // occlusion pass over the pixels the primary kernel queued
 // ------------------------------------------------------------------------------------------------
 // Scenes without an LBVH (fewer than two triangles, or a tree deeper than the stack): one wave per queued pixel,
@@ -1824,8 +1947,36 @@ static void launch_bin_ranges(hipStream_t s, const Batch& b, const DeviceScene& 
                        sc.nfine, rpw);
 }
 
+// ---- one lane per triangle: when ----
+// INV_SCATTER=0 / 1 in the environment: never / whenever possible (tests, measurements); otherwise the frames for
+// which the tile kernel would work through its candidates in batches (triangles far smaller than a pixel).
+static int scatter_env() {
+    static const int v = [] {
+        const char* e = std::getenv("INV_SCATTER");
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    return v;
+}
+
+bool scatter_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out) {
+    if (f.npix == 0 || !sc.has_bvh || !sc.slot_of || sc.height > (uint32_t)kStack || f.spp != 1u) return false;
+    if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE | INV_BLOCKS)) return false;
+    const int env = scatter_env();
+    if (env == 0 || !eye_outside_scene(f, sc)) return false;
+    if (env > 0) return true;
+    int mode = kBlocks;
+    (void)plan_tile_frame(f, sc, out, false, &mode);
+    return mode == kBatched;
+}
+
+hipError_t launch_vis_fill(hipStream_t s, unsigned long long* vis, uint64_t n) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_vis_fill, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, vis, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao,
-                             const Outputs& out, const BinMem* bins) {
+                             const Outputs& out, const BinMem* bins, unsigned long long* vis) {
     if (f.npix == 0) return hipSuccess;
     if (!sc.has_bvh || sc.height > (uint32_t)kStack) return launch_render_brute(s, f, sc, ao, out);
     if (f.flags & INV_LANE_TRAVERSAL) {
@@ -1838,6 +1989,16 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         }
         hipLaunchKernelGGL(k_render_bvh, dim3(blocks), dim3(256), 0, s, f, (const float4*)sc.triA,
                            (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, ao, out);
+        return hipGetLastError();
+    }
+    if (vis && scatter_wanted(f, sc, out)) {
+        // (nothing to try when the scene lies outside the frame: the resolve pass then stores clear values only)
+        if (f.rx1 > f.rx0 && f.ry1 > f.ry0)
+            hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 255u) / 256u), dim3(256), 0, s, f, (const float4*)sc.triA,
+                               (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, vis);
+        hipLaunchKernelGGL(k_scatter_resolve, dim3((unsigned)((f.npix + 255) / 256)), dim3(256), 0, s, f,
+                           (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
+                           (const uint32_t*)sc.slot_of, sc.ntri, vis, ao, out);
         return hipGetLastError();
     }
     int mode = kBlocks;

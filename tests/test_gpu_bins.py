@@ -82,9 +82,8 @@ def test_fine_cut_of_the_large_instanced_scene(gpu_ctx, bunny_mesh):
     scene.close()
 
 
-def test_parity_suite_with_every_draw_binned():
-    """The parity tests again with INV_BINS=1 (its own process: the library reads the variable once)."""
-    env = dict(os.environ, INV_BINS="1")
+def _parity_suite_with(**env_vars):
+    env = dict(os.environ, **env_vars)
     names = ("config1 or config2 or shading or jittered or samples_in or odd_extents or moved_camera or soup or tiny or "
              "sharding or sparse_composite or turntable or in_flight or batched_draws or overflow or camera_inside or "
              "ambient or instanced or ray_along or 8k")
@@ -95,3 +94,15 @@ def test_parity_suite_with_every_draw_binned():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
+
+
+def test_parity_suite_with_every_draw_binned():
+    """The parity tests again with INV_BINS=1 (its own process: the library reads the variable once)."""
+    _parity_suite_with(INV_BINS="1")
+
+
+def test_parity_suite_with_one_lane_per_triangle():
+    """The parity tests again with INV_SCATTER=1: every frame of one sample per pixel seen from outside the scene is
+    drawn one lane per triangle into a visibility buffer (by default only frames whose triangles are far smaller than
+    a pixel are), including shards of several ranks and frames with occlusion rays."""
+    _parity_suite_with(INV_SCATTER="1")
