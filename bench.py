@@ -476,11 +476,19 @@ def main():
         value = rays_per_frame * nframes / elapsed / 1e6
         # HBM roofline of the render kernel: every pixel's colour, depth and primitive id written once,
         # triangles (48 B) and LBVH nodes (64 B) read once per frame per GPU.
-        alg_bytes = 12 * (npix if world > 1 else w * h) + scene_bytes  # per frame
+        # (frames drawn one lane per triangle read the triangle records, 48 B each, and never touch the LBVH's nodes)
+        path = scene.draw_path(cam, R.make_params(w, h, spp=spp, flags=flags, ao_rays=ao_rays))
+        scatter = (path & 15) == R.api.PATH_SCATTER
+        read_bytes = ntri * 48 if scatter else scene_bytes
+        alg_bytes = 12 * (npix if world > 1 else w * h) + read_bytes  # per frame
         launch_bytes = alg_bytes * fpl                                 # per launch of the render kernel
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        kernel_name = ("k_render_brute" if args.brute_force else "k_render_tile_batch" if fpl > 1 and not ao_rays and spp < 4
+        kernel_name = ("k_render_brute" if args.brute_force else "k_scatter_triangles+k_scatter_resolve4" if scatter
+                       else "k_render_tile_batch" if fpl > 1 and not ao_rays and spp < 4
                        else "k_render_tile") + ("+k_ao" if ao_rays else "")
+        path_names = {R.api.PATH_BRUTE: "brute force", R.api.PATH_LANES: "one lane per ray", R.api.PATH_BLOCKS: "16x16 blocks",
+                      R.api.PATH_TILES: "8x8 tiles", R.api.PATH_TILES_BATCHED: "8x8 tiles in batches",
+                      R.api.PATH_SCATTER: "one lane per triangle + resolve"}
         result = {
             "metric": "Mrays/s (primary + AO) bunny @1080p, 1/2/4/8 MI355X; % HBM/VALU roofline",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -493,6 +501,9 @@ def main():
                        "rays_per_frame": rays_per_frame, "frames_per_step": args.frames_per_step,
                        "us_per_frame": elapsed / nframes * 1e6, "flags": int(flags),
                        "triangles": ntri, "lbvh_nodes": nnodes, "instances": side * side,
+                       # how a frame of this workload drawn on its own is traced (frames that share a launch: 16x16 blocks)
+                       "draw_path": path_names[path & 15] + (" after a binning pass" if path & R.api.PATH_BINNED else ""),
+                       "bytes_read_per_frame": read_bytes,
                        # host wall of the scene build (upload, assembly, LBVH): first (with allocations) and last of three
                        "build_ms": [build_ms[0], build_ms[-1]], "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0%s" % (

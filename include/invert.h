@@ -174,6 +174,20 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
 #define INV_NOALLOC_QUEUE_PIXELS 262144u
 int inv_render_noalloc(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out);
 
+/* Which kernels inv_render would draw this frame with (device attachments assumed): one of the INV_PATH_* values,
+ * plus INV_PATH_BINNED when a binning pass runs first.  For tests, benchmarks and reports: the pixels are the same
+ * whichever path draws them. */
+enum {
+    INV_PATH_BRUTE = 0,   /* every triangle for every ray (INV_BRUTE_FORCE, scenes without an LBVH, very deep trees) */
+    INV_PATH_LANES = 1,   /* one lane per ray with a stack (INV_LANE_TRAVERSAL) */
+    INV_PATH_BLOCKS = 2,  /* 16x16 pixel blocks, a wave per quadrant */
+    INV_PATH_TILES = 3,   /* 8x8 pixel tiles whose waves share the candidates or the samples */
+    INV_PATH_TILES_BATCHED = 4, /* 8x8 pixel tiles that work through their candidates in batches */
+    INV_PATH_SCATTER = 5, /* one lane per triangle into a visibility buffer, then a resolve pass */
+    INV_PATH_BINNED = 16u,
+};
+int inv_draw_path(const inv_scene* scene, const inv_camera* cam, const inv_params* params, uint32_t* path);
+
 /* ---- frames in flight ------------------------------------------------------------------------------------------ */
 /* The reference keeps MAX_FRAMES_IN_FLIGHT = 2 frames in flight (src/invert.cpp:241): drawFrame waits for the fence
  * of the frame slot it is about to reuse (src/invert.cpp:646), records and submits that slot's command buffer with

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INVERT_HIP_LIB") or os.path.join(_HERE, "libinvert_hip.so")
 
 LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL, SPARSE, BLOCKS = 1, 2, 4, 8, 16, 32, 64
+PATH_BRUTE, PATH_LANES, PATH_BLOCKS, PATH_TILES, PATH_TILES_BATCHED, PATH_SCATTER, PATH_BINNED = 0, 1, 2, 3, 4, 5, 16
 MAX_FRAMES_IN_FLIGHT = 4  # INV_MAX_FRAMES_IN_FLIGHT
 CONTEXT_STREAM = 0xFFFFFFFF  # INV_CONTEXT_STREAM
 OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(8)
@@ -27,7 +28,7 @@ SYMBOLS = (
     "inv_mesh_indices", "inv_mesh_pin", "inv_mesh_destroy",
     "inv_camera_reference", "inv_camera_turntable",
     "inv_scene_build", "inv_scene_build_instanced", "inv_scene_counts", "inv_scene_destroy", "inv_scene_read_lbvh", "inv_scene_read_fine_cut",
-    "inv_vertex_shader", "inv_render", "inv_render_noalloc", "inv_tile_layout", "inv_deinterleave",
+    "inv_vertex_shader", "inv_render", "inv_render_noalloc", "inv_draw_path", "inv_tile_layout", "inv_deinterleave",
     "inv_render_batch", "inv_render_in_flight", "inv_frame_wait", "inv_frames_join", "inv_frame_stream",
     "inv_scene_hit_rect", "inv_sparse_layout", "inv_deinterleave_sparse",
     "inv_write_ppm", "inv_write_png", "inv_write_pfm", "inv_write_primid",
@@ -105,6 +106,7 @@ def lib():
     L.inv_scene_read_fine_cut.argtypes = [vp, vp, C.c_uint32, u32p]
     L.inv_vertex_shader.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int]
     L.inv_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
+    L.inv_draw_path.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), u32p]
     L.inv_render_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_render_in_flight.argtypes = [vp, C.c_uint32, C.POINTER(Camera), C.POINTER(Params), C.POINTER(Outputs)]
     L.inv_render_batch.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
@@ -402,6 +404,12 @@ class Scene:
         rc = lib().inv_render(self._h, C.byref(cam), C.byref(prm), C.byref(self._dev_out))
         if rc:
             _chk(rc)
+
+    def draw_path(self, cam: Camera, prm: Params) -> int:
+        """Which kernels inv_render would draw this frame with: a PATH_* value, plus PATH_BINNED."""
+        v = C.c_uint32()
+        _chk(lib().inv_draw_path(self._h, C.byref(cam), C.byref(prm), C.byref(v)))
+        return v.value
 
     def render_noalloc(self, cam: Camera, prm: Params, color_ptr: int = 0, depth_ptr: int = 0, primid_ptr: int = 0):
         """inv_render_noalloc: the draw into device buffers without any device allocation (static occlusion queue)."""

@@ -772,6 +772,27 @@ int inv_render(inv_scene* scene, const inv_camera* cam, const inv_params* params
     return render_on(scene, scene->ctx->stream, scene->main, cam, params, out);
 }
 
+int inv_draw_path(const inv_scene* scene, const inv_camera* cam, const inv_params* params, uint32_t* path) {
+    if (!scene || !cam || !params || !path) return fail(INV_ERR_ARG, "inv_draw_path: null argument");
+    FrameK f;
+    int rc = prepare_frame(scene, cam, params, &f);
+    if (rc != INV_OK) return rc;
+    const DeviceScene& d = scene->d;
+    const Outputs none = {nullptr, nullptr, nullptr}; // (null pointers count as 16-byte aligned)
+    if ((params->flags & INV_BRUTE_FORCE) || !d.has_bvh || d.height > kStackDepth)
+        *path = INV_PATH_BRUTE;
+    else if (params->flags & INV_LANE_TRAVERSAL)
+        *path = INV_PATH_LANES;
+    else if (scatter_wanted(f, d, none))
+        *path = INV_PATH_SCATTER;
+    else {
+        const int mode = tile_mode_for(f, d, none, false);
+        *path = (mode == 0 ? INV_PATH_BLOCKS : mode == 1 ? INV_PATH_TILES : INV_PATH_TILES_BATCHED) |
+                (tile_bins_wanted(f, d, none, false) ? (uint32_t)INV_PATH_BINNED : 0u);
+    }
+    return INV_OK;
+}
+
 int inv_render_noalloc(inv_scene* scene, const inv_camera* cam, const inv_params* params, const inv_outputs* out) {
     if (!scene || !cam || !params || !out) return fail(INV_ERR_ARG, "inv_render_noalloc: null argument");
     return render_on(scene, scene->ctx->stream, scene->main, cam, params, out, true);

@@ -53,7 +53,7 @@ constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDe
 #endif
 constexpr int kAoRefill = INV_AO_REFILL; // idle lanes at which a wave takes new rays
 constexpr unsigned long long kAoChunk = 64; // occlusion rays per chunk; chunks are dealt round-robin to the waves
-constexpr int kStack = 40;        // per-lane stack entries; deeper trees use the brute-force kernel
+constexpr int kStack = (int)kStackDepth; // per-lane stack entries; deeper trees use the brute-force kernel
 constexpr int kFrontierCap = 256;  // nodes per breadth-first level kept in LDS
 constexpr int kRangeCap = 256;     // leaf ranges per tile
 // Candidate triangle records per tile (at most 64 per wave: one mask bit each).  The batched variant fills its list
@@ -1602,6 +1602,18 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= ntri) return;
     const float4 A = TA[k], B = TB[k], C = TC[k];
+    // cull BACK (src/invert.cpp:1334).  For a ray from the origin o that meets the triangle's plane at p = o + t d,
+    // t > 0, det = e1 . (d x e2) = (p - o) . (e2 x e1) / t, and (p - o) . n is the same for every p of the plane: its
+    // sign at v0 decides for all rays at once.  The terms of the cheap inside test below carry it: det = d . P0 and
+    // o - v0 = t0, so the test is t0 . P0 >= 0 (clearly so: a margin of the products' rounding keeps the doubtful).
+    float4 P0, P1, P2;
+    fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
+    {
+        const float tx = f.ox - A.x, ty = f.oy - A.y, tz = f.oz - A.z;
+        const float s = (tx * P0.x + ty * P0.y) + tz * P0.z; // = -(v0 - o) . n: positive when the front faces the eye
+        const float mag = (fabsf(tx * P0.x) + fabsf(ty * P0.y)) + fabsf(tz * P0.z);
+        if (s > 1e-4f * mag) return; // det = -s / t < 0 for every ray
+    }
     // the triangle's box exactly as the guard of mt_test forms it
     const float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
     const float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
@@ -1633,22 +1645,34 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
     const uint32_t x0 = (uint32_t)fmaxf(fx0, (float)f.rx0), y0 = (uint32_t)fmaxf(fy0, (float)f.ry0);
     const uint32_t x1 = (uint32_t)fminf(fx1, (float)f.rx1 - 1.0f), y1 = (uint32_t)fminf(fy1, (float)f.ry1 - 1.0f);
     if (x0 > x1 || y0 > y1) return;
-    // cull BACK (src/invert.cpp:1334): det = e1 . (d x e2) is linear in d and every ray direction of the rectangle is
-    // a convex combination of the directions through its corners; clearly negative at all four: no pixel can pass
+    // The cheap inside test of the tile kernel (mt_inside_pair, one record): the three dot products of the folded
+    // terms with the pixel's direction, every comparison widened by a bound on the roundings (of these products, of
+    // mt_test's own, and of the reciprocal multiplies in dir_at).  Only pixels it lets through get their exact ray
+    // and the full test, which alone decides.
+    float eps;
     {
-        const float nx = C.y * B.z - C.z * B.y, ny = C.z * B.x - C.x * B.z, nz = C.x * B.y - C.y * B.x;
-        float dmax = -INFINITY, scale = 0.0f;
+        float cdx[4], cdy[4], cdz[4], dabs = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            float dx, dy, dz;
-            dir_at(f, (c & 1) ? (float)x1 + 1.0f + m : (float)x0 - m, (c & 2) ? (float)y1 + 1.0f + m : (float)y0 - m, dx, dy, dz);
-            dmax = fmaxf(dmax, (dx * nx + dy * ny) + dz * nz);
-            scale = fmaxf(scale, (fabsf(dx * nx) + fabsf(dy * ny)) + fabsf(dz * nz));
+            dir_at(f, (c & 1) ? (float)x1 + 1.0f : (float)x0, (c & 2) ? (float)y1 + 1.0f : (float)y0, cdx[c], cdy[c], cdz[c]);
+            dabs = fmaxf(dabs, fmaxf(fmaxf(fabsf(cdx[c]), fabsf(cdy[c])), fabsf(cdz[c])));
         }
-        if (dmax < -1e-4f * scale) return;
+        eps = pair_eps(f.ox, f.oy, f.oz, dabs + dabs, A, B, C);
     }
+#ifdef INV_SC_NOLOOP
+    if (eps == 12345.0f) vis[1] = 1ull;
+    return;
+#endif
     for (uint32_t py = y0; py <= y1; py++)
         for (uint32_t px = x0; px <= x1; px++) {
+            float dx, dy, dz;
+            dir_at(f, (float)px + 0.5f, (float)py + 0.5f, dx, dy, dz);
+            const float det = __builtin_fmaf(dx, P0.x, __builtin_fmaf(dy, P0.y, dz * P0.z));
+            const float un = __builtin_fmaf(dx, P1.x, __builtin_fmaf(dy, P1.y, dz * P1.z));
+            const float vn = __builtin_fmaf(dx, P2.x, __builtin_fmaf(dy, P2.y, dz * P2.z));
+            const float e2 = eps + eps, hi = det + e2;
+            const float worst = fminf(fminf(fminf(det + eps, un + eps), fminf(hi - un, vn + eps)), (hi + eps) - (un + vn));
+            if (worst < 0.0f) continue; // (a NaN goes on to the exact test)
             if (f.nranks > 1) { // another rank's tile
                 uint64_t dummy;
                 if (!out_index(f, px, py, dummy)) continue;
@@ -1656,7 +1680,11 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
             const Ray ray = make_ray(f, px, py, 0.5f, 0.5f);
             Hit best = miss_hit();
             mt_test(f, ray, A, B, C, k, best);
+#ifndef INV_SC_NOATOMIC
             if (best.key != kMissKey) atomicMin(&vis[(size_t)py * f.w + px], (unsigned long long)best.key);
+#else
+            if (best.key == 12345ull) vis[0] = best.key;
+#endif
         }
 }
 
@@ -1695,6 +1723,57 @@ __global__ __launch_bounds__(256) void k_scatter_resolve(FrameK f, const float4*
         return;
     }
     if (live) finish_pixel(f, ao, out, i, pix, ray0, first, Bw, Cw, r, g, b);
+}
+
+// The same for whole row-major frames whose rows and buffers allow 16-byte accesses, without an occlusion pass: four
+// pixels of a row per lane, 16 bytes per attachment and store (write-through and non-temporal, like the clear: five
+// sixths of these pixels are background).
+__global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, const float4* __restrict__ TA,
+                                                          const float4* __restrict__ TB, const float4* __restrict__ TC,
+                                                          const uint32_t* __restrict__ slot_of, uint32_t ntri,
+                                                          unsigned long long* __restrict__ vis, Outputs out) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // group of four pixels
+    if (q * 4u >= f.npix) return;
+    const uint32_t pix0 = (uint32_t)(q * 4u), py = pix0 / f.w, px0 = pix0 - py * f.w;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2* const vp = (u64x2*)(vis + pix0);
+    const u64x2 k01 = vp[0], k23 = vp[1];
+    const unsigned long long keys[4] = {k01.x, k01.y, k23.x, k23.y};
+    const uint32_t bg = background_pixel(f.flags);
+    u32x4_t col = {bg, bg, bg, bg}, dep = {0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u}, pid = {~0u, ~0u, ~0u, ~0u};
+    if (k01.x != kMissKey || k01.y != kMissKey || k23.x != kMissKey || k23.y != kMissKey) { // some pixel was hit
+        const u64x2 miss2 = {kMissKey, kMissKey};
+        vp[0] = miss2, vp[1] = miss2;
+        // the four lookups, then the four records, each set in flight together: a lane's pixels are independent
+        uint32_t slot[4];
+        bool hit[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hit[j] = keys[j] != kMissKey && (uint32_t)keys[j] < ntri; // (the second test never fails for keys the first pass wrote)
+            slot[j] = hit[j] ? slot_of[(uint32_t)keys[j]] : 0u;
+        }
+        float4 A[4], B[4], C[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (hit[j]) A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
+            Hit first = miss_hit();
+            if (hit[j]) {
+                const Ray ray0 = make_ray(f, px0 + (uint32_t)j, py, 0.5f, 0.5f);
+                mt_test(f, ray0, A[j], B[j], C[j], slot[j], first); // the same test again: the same key, now with its terms
+                if (first.key != kMissKey) shade_hit(f, first, A[j], B[j], C[j], r, g, b);
+            }
+            col[j] = pack_pixel(f.flags, r, g, b);
+            dep[j] = (uint32_t)(first.key >> 32), pid[j] = (uint32_t)first.key;
+        }
+    }
+#define INV_ST16_NT(p, v) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory")
+    if (out.color) INV_ST16_NT((uint32_t*)out.color + pix0, col);
+    if (out.depth) INV_ST16_NT((uint32_t*)out.depth + pix0, dep);
+    if (out.primid) INV_ST16_NT(out.primid + pix0, pid);
+#undef INV_ST16_NT
 }
 
 __global__ __launch_bounds__(256) void k_vis_fill(unsigned long long* __restrict__ vis, uint64_t n) {
@@ -1996,9 +2075,16 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         if (f.rx1 > f.rx0 && f.ry1 > f.ry0)
             hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 255u) / 256u), dim3(256), 0, s, f, (const float4*)sc.triA,
                                (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, vis);
-        hipLaunchKernelGGL(k_scatter_resolve, dim3((unsigned)((f.npix + 255) / 256)), dim3(256), 0, s, f,
-                           (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
-                           (const uint32_t*)sc.slot_of, sc.ntri, vis, ao, out);
+        const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+        if (f.rowmajor && f.nranks == 1 && !ao.rays && f.w % 4u == 0 && aligned16(out.color) && aligned16(out.depth) &&
+            aligned16(out.primid))
+            hipLaunchKernelGGL(k_scatter_resolve4, dim3((unsigned)((f.npix / 4 + 255) / 256)), dim3(256), 0, s, f,
+                               (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
+                               (const uint32_t*)sc.slot_of, sc.ntri, vis, out);
+        else
+            hipLaunchKernelGGL(k_scatter_resolve, dim3((unsigned)((f.npix + 255) / 256)), dim3(256), 0, s, f,
+                               (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
+                               (const uint32_t*)sc.slot_of, sc.ntri, vis, ao, out);
         return hipGetLastError();
     }
     int mode = kBlocks;
@@ -2022,6 +2108,12 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         INV_LAUNCH_TILE(kBlocks);
 #undef INV_LAUNCH_TILE
     return hipGetLastError();
+}
+
+int tile_mode_for(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch) {
+    int mode = kBlocks;
+    (void)plan_tile_frame(f, sc, out, batch, &mode);
+    return mode; // 0: 16x16 blocks, 1: 8x8 tiles, 2: 8x8 tiles worked through in batches
 }
 
 bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out) {

@@ -39,6 +39,7 @@ def config3_frame(oracle, bunny_scene, bunny_mesh):
 
 def test_config3_4k_16spp_against_oracle(bunny_scene, config3_frame):
     prm = R.make_params(W4K, H4K, spp=16, seed=0, flags=FLAGS)
+    assert bunny_scene.draw_path(R.camera_reference(W4K, H4K), prm) == R.api.PATH_TILES
     got = bunny_scene.render(R.camera_reference(W4K, H4K), prm)
     common.assert_frames_equal(got, config3_frame, "config 3")
     hits = got[2] != 0xFFFFFFFF
@@ -75,9 +76,19 @@ def test_config4_1024_instances(oracle, gpu_ctx, bunny_path, bunny_mesh):
         cam = common.pulled_back_camera(R.camera_reference(w, h), 0.27 * side)
         ocam = oracle.Camera.from_buffer_copy(bytes(cam))
         prm = R.make_params(w, h, flags=FLAGS)
+        # eleven triangles per pixel under the instances: drawn one lane per triangle
+        assert scene.draw_path(cam, prm) == R.api.PATH_SCATTER
         got = scene.render(cam, prm)
         want = oracle.render_bvh(fx, fi, ocam, common.oracle_params(oracle, prm))
         common.assert_frames_equal(got, want, "config 4")
+        # the same frame through the tile kernel (a binning pass, then 8x8 tiles in batches): two samples per pixel
+        # are outside what the triangle pass takes, and sample 0 alone decides depth and primitive id
+        prm2 = R.make_params(w, h, spp=2, seed=1, flags=FLAGS)
+        assert scene.draw_path(cam, prm2) == R.api.PATH_TILES_BATCHED | R.api.PATH_BINNED
+        got2 = scene.render(cam, prm2)
+        assert np.array_equal(got2[2], want[2]) and np.array_equal(got2[1].view(np.uint32), want[1].view(np.uint32))
+        want2 = oracle.render_bvh(fx, fi, ocam, common.oracle_params(oracle, prm2))
+        common.assert_frames_equal(got2, want2, "config 4, two samples per pixel")
         hits = got[2] != 0xFFFFFFFF
         assert hits.sum() > 300000 and len(np.unique(got[2][hits] // 4968)) == 1024  # every instance is seen
         # the same frame as a batch of two on a frame slot (the form bench.py times for small scenes) and in parity mode
