@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
     ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
                     help="N > 1: gather only the tiles that can contain hits (sparse) or the whole frame (dense)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "c"],
+                    help="N > 1, sparse composite: torch.distributed.gather, or the library's own exchange (inv_comm_gather: "
+                         "grouped RCCL send / receive on the context's stream; staging files with --backend gloo)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on one GPU (ranks share cuda:0, gather through host memory)")
     args = ap.parse_args()
@@ -234,13 +237,17 @@ def main():
     slots_used = fif > 1 or fpl > 1  # else: plain inv_render on the context's stream
     cb = None
     grouped = sparse and args.composite_frames > 1
+    comm = None
+    if sparse and args.gather == "c":
+        comm = RD.make_comm(ctx, rank, world, "rccl" if args.backend == "nccl" else "host")
+    direct = args.backend == "nccl" or comm is not None  # the composite's own exchange moves the tiles
     if grouped:
         fpl = args.composite_frames
         cb = RD.SparseCompositeBatch(scene, cam, w, h, rank, world, frames=fpl, sets=2, tile=tile, spp=spp, flags=flags,
-                                     ao_rays=ao_rays)
+                                     ao_rays=ao_rays, comm=comm)
         npix = cb.slot_elems if rank else w * h - (world - 1) * cb.slot_elems  # pixels per frame this rank writes
     elif sparse:
-        sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=flags, ao_rays=ao_rays)
+        sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=flags, ao_rays=ao_rays, comm=comm)
         frame, gathered = sc.frame, sc.gathered
         # pixels this rank's render launch writes
         npix = sc.slot_elems if rank else w * h - (world - 1) * sc.slot_elems
@@ -311,7 +318,7 @@ def main():
     def run_groups(groups):
         for k, n in groups:
             cb.render(k, n)
-            if args.backend == "nccl":
+            if direct:
                 cb.composite(k, n)
             else:  # rehearsal: the collective runs on host copies
                 ctx.frames_join()
@@ -337,7 +344,7 @@ def main():
         if timed:
             ev1[i // every].record(stream)
         if sparse:
-            if args.backend == "nccl":
+            if direct:
                 sc.composite()
             elif sc.slot_elems:  # rehearsal: the collective runs on host copies
                 stream.synchronize()
@@ -507,7 +514,8 @@ def main():
                        # host wall of the scene build (upload, assembly, LBVH): first (with allocations) and last of three
                        "build_ms": [build_ms[0], build_ms[-1]], "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0%s" % (
-                                           args.composite, world, ", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
+                                           args.composite, world, (", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
+                                           + (", exchange through inv_comm_gather" if comm is not None else ""))
                                        if world > 1 else "1 GPU")},
             # `achieved` = algorithmic bytes of the frames drawn / wall time of the timed region: launches of different
             # frame slots overlap on the GPU, so the job's rate, not a launch's, is what the HBM interface sustained.
@@ -555,6 +563,8 @@ def main():
             # the instruction counts of the kernel's counter pass
             result["cpu_baseline"]["oracle_traversal_work"] = work
         print(json.dumps(result))
+    if comm is not None:
+        comm.close()
     scene.close()
     ctx.close()
     if world > 1:

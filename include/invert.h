@@ -258,6 +258,33 @@ int inv_deinterleave_sparse(inv_ctx* ctx, const inv_params* params, const uint32
                             uint64_t rank_stride, uint64_t plane_stride, uint32_t nplanes, void* frame,
                             uint64_t frame_plane_stride);
 
+/* ---- the exchange of a multi-GPU composite, from C ------------------------------------------------------------ */
+/* No counterpart in the reference (one GPU).  One process per GPU; each renders its shard with inv_render (params
+ * rank / nranks), then every rank calls inv_comm_gather and rank 0 puts the tiles into its frame with inv_deinterleave
+ * or inv_deinterleave_sparse.  Two transports:
+ *   inv_comm_create_rccl  grouped ncclSend / ncclRecv to rank 0 on the context's stream (only enqueues: the call
+ *                         returns before the data has moved; later work on the context's stream is ordered behind it).
+ *                         Rank 0 makes an id with inv_comm_unique_id and hands its INV_COMM_ID_BYTES bytes to the other
+ *                         ranks by whatever means the launcher has (a file, MPI, a socket); creating the communicator
+ *                         is collective: every rank must call it.  librccl is opened at run time (INV_ERR_UNSUPPORTED
+ *                         if it cannot be).
+ *   inv_comm_create_host  staging through files in directory `dir`, which every rank must reach (/dev/shm on one
+ *                         node): for rehearsing the several-rank path where RCCL cannot run (it refuses two ranks on one
+ *                         GPU), and as a fallback.  Blocking: the call returns when the data has arrived. */
+typedef struct inv_comm inv_comm;
+#define INV_COMM_ID_BYTES 128
+enum { INV_COMM_RCCL = 0, INV_COMM_HOST = 1 };
+int inv_comm_unique_id(void* id);
+int inv_comm_create_rccl(inv_ctx* ctx, const void* id, uint32_t rank, uint32_t nranks, inv_comm** out);
+int inv_comm_create_host(inv_ctx* ctx, const char* dir, uint32_t rank, uint32_t nranks, inv_comm** out);
+/* Every rank > 0 sends `count` 4-byte elements from `send`; rank 0 receives rank r's at element r * rank_stride of `recv`
+ * (its own part is not touched, `send` may be NULL there).  Device pointers on the communicator's GPU.  All ranks make
+ * the same sequence of calls with the same `count`. */
+int inv_comm_gather(inv_comm* comm, const void* send, uint64_t count, void* recv, uint64_t rank_stride);
+int inv_comm_destroy(inv_comm* comm);
+/* The GPU a context was created on. */
+int inv_ctx_device(inv_ctx* ctx, int* device);
+
 /* ---- making the attachments inspectable (host buffers) ----------------------------------------------------------- */
 /* The reference presents its colour image (src/invert.cpp:674-683) and stores nothing.  Binary PPM (P6) of a colour
  * buffer (pass INV_RGBA in `flags` if it was rendered with it), little-endian PFM of a depth buffer, and a raw

@@ -23,7 +23,8 @@ OK, ERR_ARG, ERR_IO, ERR_FORMAT, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEV
 
 # every symbol include/invert.h declares
 SYMBOLS = (
-    "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize", "inv_ctx_trim", "inv_ctx_stream",
+    "inv_ctx_create", "inv_ctx_destroy", "inv_ctx_synchronize", "inv_ctx_trim", "inv_ctx_stream", "inv_ctx_device",
+    "inv_comm_unique_id", "inv_comm_create_rccl", "inv_comm_create_host", "inv_comm_gather", "inv_comm_destroy",
     "inv_mesh_load_obj", "inv_mesh_load_obj_general", "inv_mesh_parse_obj", "inv_mesh_from_arrays", "inv_mesh_counts", "inv_mesh_vertices",
     "inv_mesh_indices", "inv_mesh_pin", "inv_mesh_destroy",
     "inv_camera_reference", "inv_camera_turntable",
@@ -81,6 +82,12 @@ def lib():
     L.inv_ctx_synchronize.argtypes = [vp]
     L.inv_ctx_trim.argtypes = [vp]
     L.inv_ctx_stream.argtypes = [vp, C.POINTER(vp)]
+    L.inv_ctx_device.argtypes = [vp, C.POINTER(C.c_int)]
+    L.inv_comm_unique_id.argtypes = [vp]
+    L.inv_comm_create_rccl.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.inv_comm_create_host.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.inv_comm_gather.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+    L.inv_comm_destroy.argtypes = [vp]
     L.inv_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_mesh_load_obj_general.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.inv_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -293,6 +300,50 @@ class Context:
         """inv_ctx_destroy; raises while scenes built on this context are still open (close them first)."""
         if self._h:
             _chk(lib().inv_ctx_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+COMM_ID_BYTES = 128  # INV_COMM_ID_BYTES
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the RCCL id every rank's Comm.rccl needs (hand it to the other ranks, e.g. with a broadcast)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(lib().inv_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """The exchange step of a multi-GPU composite through the C ABI (inv_comm_*): RCCL, or host staging files."""
+
+    def __init__(self, handle, ctx, rank, nranks):
+        self._h, self.ctx, self.rank, self.nranks = handle, ctx, rank, nranks
+
+    @staticmethod
+    def rccl(ctx: "Context", unique_id: bytes, rank: int, nranks: int) -> "Comm":
+        h = C.c_void_p()
+        _chk(lib().inv_comm_create_rccl(ctx._h, C.c_char_p(unique_id), rank, nranks, C.byref(h)))
+        return Comm(h, ctx, rank, nranks)
+
+    @staticmethod
+    def host(ctx: "Context", directory: str, rank: int, nranks: int) -> "Comm":
+        h = C.c_void_p()
+        _chk(lib().inv_comm_create_host(ctx._h, os.fsencode(directory), rank, nranks, C.byref(h)))
+        return Comm(h, ctx, rank, nranks)
+
+    def gather(self, send_ptr: int, count: int, recv_ptr: int = 0, rank_stride: int = 0):
+        """Every rank > 0 sends `count` 4-byte elements; rank 0 receives rank r's at recv + r * rank_stride."""
+        _chk(lib().inv_comm_gather(self._h, C.c_void_p(send_ptr or None), count, C.c_void_p(recv_ptr or None), rank_stride))
+
+    def close(self):
+        if self._h:
+            lib().inv_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):

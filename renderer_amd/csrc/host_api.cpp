@@ -256,6 +256,12 @@ int inv_ctx_stream(inv_ctx* ctx, void** hip_stream) {
     return INV_OK;
 }
 
+int inv_ctx_device(inv_ctx* ctx, int* device) {
+    if (!ctx || !device) return fail(INV_ERR_ARG, "inv_ctx_device: null argument");
+    *device = ctx->device;
+    return INV_OK;
+}
+
 int inv_ctx_trim(inv_ctx* ctx) {
     if (!ctx) return fail(INV_ERR_ARG, "inv_ctx_trim: ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));

@@ -44,6 +44,20 @@ def order_context_stream_after_current(ctx: api.Context) -> None:
     torch.cuda.ExternalStream(ctx.stream).wait_event(ev)
 
 
+def make_comm(ctx: api.Context, rank: int, world: int, transport: str = "rccl") -> api.Comm:
+    """The library's own communicator (inv_comm_*: grouped RCCL send / receive on the context's stream, or staging
+    files) for the ranks of the initialised torch.distributed group, which only carries the rendezvous here: rank 0's
+    RCCL id, or the name of a fresh directory under /dev/shm."""
+    if transport == "rccl":
+        box = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return api.Comm.rccl(ctx, box[0], rank, world)
+    import tempfile
+    box = [tempfile.mkdtemp(prefix="inv_comm_", dir="/dev/shm") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return api.Comm.host(ctx, box[0], rank, world)
+
+
 def shard_params(width, height, rank, world, tile=64, **kw) -> api.Params:
     """Params for this rank: it renders the tiles with tile_id % world == rank."""
     return api.make_params(width, height, tile=tile, rank=rank, nranks=world, **kw)
@@ -90,10 +104,11 @@ class SparseComposite:
     """
 
     def __init__(self, scene: api.Scene, cam: api.Camera, width: int, height: int, rank: int, world: int,
-                 tile: int = 64, device="cuda", **params):
+                 tile: int = 64, device="cuda", comm: api.Comm | None = None, **params):
         if world < 2:
             raise ValueError("the sparse composite needs at least two ranks")
         self.scene, self.cam, self.rank, self.world = scene, cam, rank, world
+        self.comm = comm  # None: torch.distributed.gather; else the library's own exchange on the context's stream
         flags = params.pop("flags", 0) | api.SPARSE
         self.prm = api.make_params(width, height, tile=tile, rank=rank, nranks=world, flags=flags, **params)
         self.prm0 = api.make_params(width, height, tile=tile, rank=0, nranks=world, flags=flags)
@@ -121,6 +136,10 @@ class SparseComposite:
     def gather(self):
         if self.slot_elems == 0:
             return  # nothing on screen: rank 0's frame is already complete
+        if self.comm is not None:  # same stream as the draw and the copy: nothing to order
+            n = 3 * self.slot_elems
+            self.comm.gather(self.planes.data_ptr(), n, self.gathered.data_ptr() if self.rank == 0 else 0, n)
+            return
         if self.planes.is_cuda:
             order_current_stream_after(self.scene.ctx)  # the collective reads what the draw wrote
         if self.rank == 0:
@@ -159,9 +178,10 @@ class SparseCompositeBatch:
     """
 
     def __init__(self, scene: api.Scene, cam: api.Camera, width: int, height: int, rank: int, world: int,
-                 frames: int = 8, sets: int = 2, tile: int = 32, device="cuda", **params):
+                 frames: int = 8, sets: int = 2, tile: int = 32, device="cuda", comm: api.Comm | None = None, **params):
         if world < 2:
             raise ValueError("the sparse composite needs at least two ranks")
+        self.comm = comm  # None: torch.distributed.gather; else the library's own exchange on the context's stream
         if not 1 <= sets <= api.MAX_FRAMES_IN_FLIGHT:
             raise ValueError("sets must be between 1 and %d" % api.MAX_FRAMES_IN_FLIGHT)
         self.scene, self.cam, self.rank, self.world, self.nframes, self.nsets = scene, cam, rank, world, frames, sets
@@ -204,6 +224,10 @@ class SparseCompositeBatch:
         self.scene.ctx.frames_join()  # the context's stream waits for the slots' draws
         if self.slot_elems == 0:
             return  # nothing on screen: rank 0's frames are already complete
+        if self.comm is not None:  # the first n frames of every rank's part: n * 3 * s elements, parts F * 3 * s apart
+            s, F = self.slot_elems, self.nframes
+            self.comm.gather(self.planes[k].data_ptr(), n * 3 * s, self.gathered[k].data_ptr() if self.rank == 0 else 0, F * 3 * s)
+            return
         order_current_stream_after(self.scene.ctx)
         if self.rank == 0:
             dist.gather(self.planes[k][:n], [self.gathered[k][r, :n] for r in range(self.world)], dst=0)

@@ -51,3 +51,14 @@ def test_bench_grouped_composite_on_one_gpu(nranks, frames, steps, warmup):
     r = _run(nranks, "--composite-frames", str(frames), steps=steps, warmup=warmup)
     assert r["n_gpus"] == nranks and r["steps"] == steps and r["config"]["hit_pixels"] == 25139
     assert (("%d frames per gather" % frames) in r["config"]["parallelism"]) == (frames > 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("nranks,extra", [(2, ("--composite-frames", "1")), (3, ("--composite-frames", "4"))])
+def test_bench_with_the_librarys_own_exchange(nranks, extra):
+    """--gather c: the tiles travel through inv_comm_gather (here its staging files; RCCL send / receive with the
+    nccl backend) instead of torch.distributed.gather, frame by frame and in groups of four."""
+    r = _run(nranks, "--gather", "c", *extra, steps=5, warmup=2)
+    assert r["n_gpus"] == nranks and r["config"]["hit_pixels"] == 25139
+    assert "inv_comm_gather" in r["config"]["parallelism"]
