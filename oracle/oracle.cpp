@@ -1028,6 +1028,25 @@ int orc_lbvh_build(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t
     return 0;
 }
 
+// The occlusion rays of one pixel: origin offset and the `rays` directions ao_factor would trace for a hit on a
+// triangle with edges e1, e2 (hit point at the origin, guard pad 0), without tracing anything.
+void orc_ao_directions(const float e1[3], const float e2[3], uint32_t pix, uint32_t seed, uint32_t rays, float* w3) {
+    Frame f = {};
+    f.pad = 0.0f;
+    AoParams ao = {rays, 1.0f, seed};
+    Ray r = {};
+    Best b = {};
+    b.t = 0.0f;
+    Tri tr = {};
+    tr.e1 = {e1[0], e1[1], e1[2]}, tr.e2 = {e2[0], e2[1], e2[2]};
+    uint32_t k = 0;
+    (void)ao_factor(f, ao, pix, r, b, tr, [&](const V3&, const V3& w, float) {
+        w3[3 * k] = w.x, w3[3 * k + 1] = w.y, w3[3 * k + 2] = w.z;
+        k++;
+        return false;
+    });
+}
+
 uint8_t orc_srgb8(float x) { return srgb8(x); }
 uint32_t orc_hash32(uint32_t x) { return hash32(x); }
 void orc_sample_offset(uint32_t pixel, uint32_t sample, uint32_t seed, float* sx, float* sy) {

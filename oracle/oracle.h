@@ -106,6 +106,7 @@ int orc_lbvh_build(const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t
                    uint64_t* morton, uint32_t* order, uint32_t* child, uint32_t* parent,
                    uint32_t* leaf_parent, float* box);
 
+void orc_ao_directions(const float e1[3], const float e2[3], uint32_t pix, uint32_t seed, uint32_t rays, float* w3);
 uint8_t orc_srgb8(float x);
 uint32_t orc_hash32(uint32_t x);
 void orc_sample_offset(uint32_t pixel, uint32_t sample, uint32_t seed, float* sx, float* sy);

@@ -66,6 +66,8 @@ def lib():
         L.orc_raster.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Camera), C.c_uint32,
                                  C.c_uint32, C.c_void_p, C.c_void_p, up]
         L.orc_lbvh_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        L.orc_ao_directions.argtypes = [fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_ao_directions.restype = None
         L.orc_srgb8.argtypes = [C.c_float]
         L.orc_srgb8.restype = C.c_uint8
         L.orc_hash32.argtypes = [C.c_uint32]
@@ -188,6 +190,19 @@ def lbvh_build(xyzw, idx):
     _chk(lib().orc_lbvh_build(xyzw.ctypes.data, xyzw.shape[0], idx.ctypes.data, idx.size, out["morton"].ctypes.data,
                               out["order"].ctypes.data, out["child"].ctypes.data, out["parent"].ctypes.data,
                               out["leaf_parent"].ctypes.data, out["box"].ctypes.data), "orc_lbvh_build")
+    return out
+
+
+def hash32(x: int) -> int:
+    return int(lib().orc_hash32(x & 0xFFFFFFFF))
+
+
+def ao_directions(e1, e2, pix: int, seed: int, rays: int) -> np.ndarray:
+    """Directions of the occlusion rays of pixel `pix` on a triangle with edges e1, e2: float32 [rays, 3]."""
+    a = (C.c_float * 3)(*[float(v) for v in e1])
+    b = (C.c_float * 3)(*[float(v) for v in e2])
+    out = np.zeros((rays, 3), np.float32)
+    lib().orc_ao_directions(a, b, pix, seed, rays, out.ctypes.data)
     return out
 
 

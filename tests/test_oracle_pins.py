@@ -247,3 +247,72 @@ def test_occlusion_oracle_bvh_equals_brute_force(oracle, bunny_mesh):
     with_ao = oracle.render_bruteforce(txyzw, tidx, c, oracle.make_params(64, 64, ao_rays=32))
     without = oracle.render_bruteforce(txyzw, tidx, c, oracle.make_params(64, 64))
     assert np.array_equal(with_ao[0], without[0]) and (with_ao[2] != 0xFFFFFFFF).sum() > 20
+
+
+def _bunny_from_the_decimal_fields():
+    """The mesh without the oracle: the loader's float32 arithmetic restated in numpy (test_loader_restatement_in_numpy)."""
+    fo = objfmt.bunny()
+    whole = (fo.mant // 10_000_000).astype(np.float32)
+    frac = (fo.mant % 10_000_000).astype(np.float32)
+    norm = np.ones(fo.mant.shape, np.float32)
+    for step in range(int(fo.expo.max())):
+        active = fo.expo > step
+        norm = np.where(active & fo.eneg, (norm / np.float32(10.0)).astype(np.float32), norm)
+        norm = np.where(active & ~fo.eneg, (norm * np.float32(10.0)).astype(np.float32), norm)
+    val = ((whole + (frac / np.float32(10000000.0)).astype(np.float32)).astype(np.float32) * norm).astype(np.float32)
+    val = (val * np.where(fo.neg, np.float32(-1.0), np.float32(1.0))).astype(np.float32)
+    return val, (fo.faces - 1).astype(np.int64)
+
+
+@pytest.mark.parametrize("size,golden,covered", [("512x512", "bunny_512", 5651), ("1920x1080", "bunny_1080_rect", 25139)])
+def test_goldens_against_the_numpy_rasteriser(size, golden, covered):
+    """Every pixel of configs 1 and 2: primitive id, depth and the stored colour bytes of the committed goldens
+    against a double-precision rasteriser that shares no code with the oracle (tests/raster_np.py), fed with the
+    mesh from the decimal fields and the pinned matrices.  Primitive ids agree except where a pixel centre lies
+    within rounding of an edge; depth within a few float32 roundings (99.9 % of the pixels within 4); blue within 1 LSB (8-bit sRGB); red, green and
+    alpha 255; background (0, 0, 0, 255) in B, G, R, A order."""
+    import raster_np
+    w, h = [int(v) for v in size.split("x")]
+    xyz, faces = _bunny_from_the_decimal_fields()
+    cam = common.pins()["cameras"][size]
+    primid, depth, blue, _, nfront = raster_np.rasterise(xyz, faces, common.unhex(cam["model"]), common.unhex(cam["view"]),
+                                                         common.unhex(cam["proj"]), w, h)
+    assert nfront == 2565 and int((primid != 0xFFFFFFFF).sum()) == covered
+    gc, gd, gp = common.golden_frame(golden)
+    differ = gp != primid
+    assert int(differ.sum()) <= 4
+    same = ~differ & (gp != 0xFFFFFFFF)
+    # (float32 ray casting against double-precision interpolation: a few roundings, more on a triangle seen nearly
+    # edge-on, where the ray parameter is a quotient of two small numbers: one pixel of the 25 139 is 18 units off)
+    err = np.abs(gd[same].astype(np.float64) - depth[same]) / 2.0 ** -24
+    assert np.percentile(err, 99.9) < 4.0 and err.max() < 32.0
+    want_b = raster_np.srgb8(blue)
+    assert np.abs(gc[..., 0][same].astype(np.int64) - want_b[same]).max() <= 1
+    assert (gc[..., 0][same].astype(np.int64) == want_b[same]).mean() > 0.97  # off by one only at rounding boundaries
+    hit = gp != 0xFFFFFFFF
+    assert (gc[..., 1][hit] == 255).all() and (gc[..., 2][hit] == 255).all() and (gc[..., 3] == 255).all()
+    assert (gc[~hit] == [0, 0, 0, 255]).all() and (gd[~hit] == 1.0).all()
+
+
+def test_lambert_and_invert_against_numpy(oracle, bunny_mesh):
+    """The build-defined shading on top of the reference's colour: (1, 1, 10 z) times max(0, n . -cameraAngle) with the
+    triangle's geometric normal (cameraAngle = (0, 0, -1), src/invert.cpp:633), sRGB-encoded, then 255 - c on R, G, B:
+    the oracle's frame against the numpy rasteriser's interpolated colour and a float64 evaluation, within 1 LSB."""
+    import raster_np
+    w, h = 640, 360
+    xyz, faces = _bunny_from_the_decimal_fields()
+    cam = oracle.camera_reference(w, h)
+    primid, _, blue, lam, _ = raster_np.rasterise(xyz, faces, cam.model, cam.view, cam.proj, w, h, light=(0.0, 0.0, 1.0))
+    for flags in (1, 3, 2):  # Lambert, Lambert + invert, invert alone
+        color, _, op = oracle.render_bvh(*bunny_mesh, cam, oracle.make_params(w, h, flags=flags))
+        same = (op == primid) & (op != 0xFFFFFFFF)
+        assert int((op != primid).sum()) <= 4 and same.sum() > 2500
+        L = lam if flags & 1 else np.ones_like(lam)
+        want = np.stack([raster_np.srgb8(np.clip(blue, 0.0, 1.0) * L), raster_np.srgb8(L), raster_np.srgb8(L)], axis=-1)  # B, G, R
+        if flags & 2:
+            want = 255 - want
+        diff = np.abs(color[..., :3][same].astype(np.int64) - want[same])
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.97
+        assert (color[..., 3] == 255).all()
+        bg = 255 if flags & 2 else 0
+        assert (color[..., :3][op == 0xFFFFFFFF] == bg).all()
