@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--gather", default="torch", choices=["torch", "c"],
                     help="N > 1, sparse composite: torch.distributed.gather, or the library's own exchange (inv_comm_gather: "
                          "grouped RCCL send / receive on the context's stream; staging files with --backend gloo)")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="N > 1: skip the short passes over the heavier workloads (4K with 16 samples, occlusion rays "
+                         "from close by) that follow the timed region and show where sharding pays")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on one GPU (ranks share cuda:0, gather through host memory)")
     args = ap.parse_args()
@@ -456,6 +459,68 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    # Several ranks: the headline frame is bound by rank 0's own stores, so sharding cannot pay there; these short
+    # passes (not part of `value`) time the heavier workloads the same way: the sharded draw alone, the draw plus the
+    # composite, and the whole frame on one GPU (rank 0 alone, the others idle), max over ranks.
+    extra = {}
+    if world > 1 and sparse and not args.no_extra_workloads:
+        for name in ("bunny_4k_16spp", "bunny_1080p_ao64_closeup"):
+            xw = WORKLOADS[name]
+            ew, eh = xw["width"], xw["height"]
+            ecam = R.camera_reference(ew, eh)
+            if "view_translation" in xw:
+                ecam.view[12], ecam.view[13], ecam.view[14] = xw["view_translation"]
+            kw = dict(spp=xw["spp"], flags=xw["flags"], ao_rays=xw.get("ao_rays", 0))
+            esc = RD.SparseComposite(scene, ecam, ew, eh, rank, world, tile=32, comm=comm, **kw)
+
+            def composite_once():
+                if direct:
+                    esc.composite()
+                elif esc.slot_elems:  # rehearsal: the collective runs on host copies
+                    stream.synchronize()
+                    host = RD.gather_to_rank0(esc.planes.cpu(), rank, world)
+                    if rank == 0:
+                        esc.gathered.copy_(host)
+                    esc.scatter_received()
+
+            def timed(body, n):
+                torch.cuda.synchronize()
+                dist.barrier()
+                t_0 = time.perf_counter()
+                for _ in range(n):
+                    body()
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt[0]) / n * 1e3
+
+            def both():
+                esc.render()
+                composite_once()
+
+            for _ in range(3):
+                both()
+            n_x = 20
+            render_ms = timed(esc.render, n_x)
+            both_ms = timed(both, n_x)
+            one = torch.empty(3, eh * ew, dtype=torch.int32, device="cuda") if rank == 0 else None
+            eprm = R.make_params(ew, eh, **kw)
+
+            def alone():
+                if rank == 0:
+                    scene.render_device(ecam, eprm, one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr())
+
+            alone()
+            one_ms = timed(alone, n_x)
+            both()
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(one, esc.frame)) if rank == 0 else True
+            extra[name] = {"render_only_ms": render_ms, "render_plus_gather_ms": both_ms, "one_gpu_ms": one_ms,
+                           "composite_equals_one_gpu_frame": ok, "frames_timed": n_x}
+            if rank == 0 and not ok:
+                raise SystemExit("extra workload %s: the composite differs from the single-GPU frame" % name)
+            del esc, one
+
     if world > 1 and rank == 0:
         # the composite must equal the same frame rendered by this rank alone
         alone = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
@@ -546,6 +611,8 @@ def main():
         # VALU side: utilisation from the newest committed rocprofv3 counter pass of this workload (the counters
         # cannot be read inside this process), or None
         result["roofline"]["valu"] = pmc_valu(args.workload, world, kernel_name.split("+")[-1])
+        if extra:
+            result["extra_workloads"] = extra
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
             base, oracle_out, work = cpu_baseline(wl, cams[(nframes - 1) % len(cams)] if turntable else cam)
