@@ -48,11 +48,19 @@ constexpr uint32_t kDebugSkipAfter2 = 1u << 20, kDebugSkipAfter1 = 1u << 21, kDe
 #define INV_DBG(f, bits) false
 #endif
 
-#ifndef INV_AO_REFILL
-#define INV_AO_REFILL 32
+#ifndef INV_AO_PULL
+#define INV_AO_PULL 8
 #endif
-constexpr int kAoRefill = INV_AO_REFILL; // idle lanes at which a wave takes new rays
-constexpr unsigned long long kAoChunk = 64; // occlusion rays per chunk; chunks are dealt round-robin to the waves
+#ifndef INV_AO_LEAF_NUM
+#define INV_AO_LEAF_NUM 2
+#endif
+#ifndef INV_AO_PEND
+#define INV_AO_PEND 1
+#endif
+constexpr bool kAoPend = INV_AO_PEND != 0;
+constexpr int kAoPull = INV_AO_PULL;        // idle lanes at which a wave hands out buffered occlusion rays
+constexpr int kAoLeafNum = INV_AO_LEAF_NUM; // eighths of the live lanes that must wait at a leaf before a leaf step
+constexpr unsigned long long kAoChunk = 64; // occlusion rays a wave sets up at a time (one per lane)
 constexpr int kStack = (int)kStackDepth; // per-lane stack entries; deeper trees use the brute-force kernel
 constexpr int kFrontierCap = 256;  // nodes per breadth-first level kept in LDS
 constexpr int kRangeCap = 256;     // leaf ranges per tile
@@ -1817,89 +1825,146 @@ __global__ __launch_bounds__(256) void k_ao_brute(FrameK f, AoK ao, const float4
     }
 }
 
-// LBVH scenes: a stream of rays.  A lane whose ray has ended (the first occluder ends it) takes the next ray of
-// the wave's share as soon as a quarter of the wave is idle, so short rays do not wait for the wave's longest
-// traversal.  Each step the wave does what most of its live lanes are waiting for: either one node (two child
-// boxes) or one leaf (one triangle).  The set of leaves a ray reaches does not depend on the visiting order, and
-// the per-pixel result is a sum of hits, so the image does not depend on the scheduling.
+// LBVH scenes: a stream of rays, 64 at a time ("chunks", dealt round-robin to the waves of a resident grid).
+//  * A wave sets a chunk's rays up at full width (record, direction, reciprocals) into its own LDS buffer; a lane whose
+//    ray has ended (the first occluder ends it) takes the next ray out of that buffer as soon as kAoPull lanes are
+//    idle: taking a ray is ten LDS reads, so the threshold can be low and few lanes wait for work.
+//  * Each step the wave does one thing: a node (two child boxes) for the lanes that stand at a node, or a leaf (one
+//    triangle).  A lane that reaches a leaf sets it aside (one leaf per lane) and goes on with the next node from its
+//    stack; only a lane that reaches a second leaf has to wait.  A leaf step is taken when kAoLeafNum eighths of the
+//    live lanes wait, and then every lane with a leaf set aside tests it.
+// The set of leaves a ray reaches does not depend on the visiting order (a ray that is occluded by a leaf it set
+// aside has only looked at a few more boxes than it had to), and the per-pixel result is a sum of hits, so the image
+// does not depend on the scheduling.
+#ifdef INV_AO_STATS
+__device__ unsigned long long g_ao_stats[16];
+#define AO_STAT(i, v) st[i] += (v)
+#else
+#define AO_STAT(i, v) ((void)0)
+#endif
+constexpr uint32_t kAoRayWords = 10; // per buffered ray: origin, direction, reciprocal direction, record
+constexpr uint32_t kNoNode = 0x7FFFFFFFu;
+
+// The lanes of the wave for which `p` holds (the compiler's own ballot: a scalar AND with the execution mask where
+// __ballot goes through a vector compare).
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+template <typename StackT>
 __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __restrict__ TA,
                                             const float4* __restrict__ TB, const float4* __restrict__ TC,
-                                            const float4* __restrict__ nodes, Outputs out) {
-    extern __shared__ uint32_t s_stack[]; // one column per lane, (tree height + 1) entries
-    uint32_t* const stack = s_stack + threadIdx.x;
+                                            const uint4* __restrict__ qnodes, QGrid grid, Outputs out) {
+    extern __shared__ uint32_t s_dyn[]; // [4 waves][kAoRayWords][64] ray buffers, then the stacks: one column per lane
     const uint32_t lane = threadIdx.x & 63u;
+    float* const rb = (float*)s_dyn + (threadIdx.x >> 6) * (kAoRayWords * 64u);
+    StackT* const stack = (StackT*)(s_dyn + 4u * kAoRayWords * 64u) + threadIdx.x;
+    // a child reference on the stack: scenes of fewer than 32 768 triangles keep it in 16 bits (leaf flag in bit 15)
+    const auto packed = [](uint32_t c) -> StackT {
+        return sizeof(StackT) == 4 ? (StackT)c : (StackT)((c & 0x7FFFu) | ((c >> 16) & 0x8000u));
+    };
+    const auto unpacked = [](StackT v) -> uint32_t {
+        return sizeof(StackT) == 4 ? (uint32_t)v : (((uint32_t)v & 0x7FFFu) | (((uint32_t)v & 0x8000u) << 16));
+    };
     const uint64_t total = (uint64_t)(*ao.count) * ao.rays;
+    const uint64_t nchunks = (total + (kAoChunk - 1)) / kAoChunk;
     const bool narrow = total < 0xFFFFFFFFull; // ray index -> (record, ray) without a 64-bit division
     const float4* queue = (const float4*)ao.queue;
     const float grow = 2.0f * f.pad, tlim = ao.tmax * 1.0001f;
     const uint32_t hseed = hash32(f.seed ^ 0xA0761D65u);
-    bool active = false, more = total != 0;
-    uint64_t cur = 0, end = 0; // the wave's current chunk of ray indices (wave-uniform)
     const uint64_t nwaves = (uint64_t)gridDim.x * 4u;
-    uint64_t chunk = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); // next chunk this wave takes
-    uint32_t rec = 0, node = 0, sp = 0;
+    // the chunk this wave sets up next: the same in every lane, and said so, so that it and what follows from it (the
+    // buffer's fill state, the tests on it) are kept in scalar registers
+    uint64_t chunk = (uint64_t)blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t bcur = 0, bend = 0;   // rays of the wave's buffer not yet handed to a lane (wave-uniform)
+    uint32_t active = 0; // 1 while the lane holds a ray (an integer: its ballot is then a single vector compare)
+#ifdef INV_AO_STATS
+    unsigned long long st[12] = {};
+#endif
+    uint32_t rec = 0, node = 0, sp = 0, pend = 0;
     float ox = 0, oy = 0, oz = 0, wx = 0, wy = 0, wz = 0;
-    RaySlabs rs = {};
+    RaySlabs rs = {}; // in grid units
     for (;;) {
-        const uint64_t idle = __ballot(!active);
-        if (more && __popcll(idle) >= kAoRefill) {
-            if (cur == end) { // next chunk of this wave: chunks are dealt round-robin over the grid's waves
+        const uint64_t idle = ballot64(active == 0u);
+        const uint32_t nidle = (uint32_t)__builtin_popcount((uint32_t)idle) + (uint32_t)__builtin_popcount((uint32_t)(idle >> 32));
+        if (nidle >= (uint32_t)kAoPull && (bcur < bend || chunk < nchunks)) {
+            AO_STAT(6, 1);
+            if (bcur == bend) { // set the next chunk's rays up, every lane one
+                AO_STAT(7, 1);
                 const uint64_t base = chunk * kAoChunk;
-                chunk += nwaves;
-                cur = base < total ? base : total;
-                end = base + kAoChunk < total ? base + kAoChunk : total;
-            }
-            const uint64_t g = cur + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            cur = cur + (uint32_t)__popcll(idle) < end ? cur + (uint32_t)__popcll(idle) : end;
-            if (cur == end && chunk * kAoChunk >= total) more = false;
-            if (!active) {
-                if (g < end) {
-                    uint32_t k;
+                const uint32_t n = total - base < kAoChunk ? (uint32_t)(total - base) : (uint32_t)kAoChunk;
+                if (lane < n) {
+                    const uint64_t g = base + lane;
+                    uint32_t r, k;
                     if (narrow)
-                        rec = (uint32_t)g / ao.rays, k = (uint32_t)g % ao.rays;
+                        r = (uint32_t)g / ao.rays, k = (uint32_t)g % ao.rays;
                     else
-                        rec = (uint32_t)(g / ao.rays), k = (uint32_t)(g % ao.rays);
-                    const float4 q0 = queue[3 * (size_t)rec], q1 = queue[3 * (size_t)rec + 1];
-                    const uint32_t pix = __float_as_uint(queue[3 * (size_t)rec + 2].y);
+                        r = (uint32_t)(g / ao.rays), k = (uint32_t)(g % ao.rays);
+                    const float4 q0 = queue[3 * (size_t)r], q1 = queue[3 * (size_t)r + 1];
+                    const uint32_t pix = __float_as_uint(queue[3 * (size_t)r + 2].y);
                     const float nrm[3] = {q1.x, q1.y, q1.z};
                     float w[3];
                     ao_direction(nrm, hash32(pix ^ hseed), k, ao.rays, w);
-                    ox = q0.x, oy = q0.y, oz = q0.z;
-                    wx = w[0], wy = w[1], wz = w[2];
-                    rs = make_slabs(ox, oy, oz, wx, wy, wz, grow);
-                    node = 0, sp = 0;
-                    active = true;
+                    rb[0 * 64 + lane] = q0.x, rb[1 * 64 + lane] = q0.y, rb[2 * 64 + lane] = q0.z;
+                    rb[3 * 64 + lane] = w[0], rb[4 * 64 + lane] = w[1], rb[5 * 64 + lane] = w[2];
+                    rb[6 * 64 + lane] = slab_reciprocal(w[0]);
+                    rb[7 * 64 + lane] = slab_reciprocal(w[1]);
+                    rb[8 * 64 + lane] = slab_reciprocal(w[2]);
+                    rb[9 * 64 + lane] = __uint_as_float(r);
                 }
+                bcur = 0, bend = n;
+                chunk += nwaves;
+                __builtin_amdgcn_wave_barrier();
             }
+            const uint32_t idx = bcur + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && idx < bend) {
+                ox = rb[0 * 64 + idx], oy = rb[1 * 64 + idx], oz = rb[2 * 64 + idx];
+                wx = rb[3 * 64 + idx], wy = rb[4 * 64 + idx], wz = rb[5 * 64 + idx];
+                const float ix = rb[6 * 64 + idx], iy = rb[7 * 64 + idx], iz = rb[8 * 64 + idx];
+                rec = __float_as_uint(rb[9 * 64 + idx]);
+                // plane k of axis a is met at (org + k * step - o) / d = k * (step / d) - (o - org) / d
+                rs.ix = grid.step[0] * ix, rs.iy = grid.step[1] * iy, rs.iz = grid.step[2] * iz;
+                rs.clx = ((ox + grow) - grid.org[0]) * ix, rs.cly = ((oy + grow) - grid.org[1]) * iy;
+                rs.clz = ((oz + grow) - grid.org[2]) * iz;
+                rs.chx = ((ox - grow) - grid.org[0]) * ix, rs.chy = ((oy - grow) - grid.org[1]) * iy;
+                rs.chz = ((oz - grow) - grid.org[2]) * iz;
+                node = 0, sp = 0, pend = 0;
+                active = 1u;
+            }
+            bcur = bcur + nidle < bend ? bcur + nidle : bend;
+            __builtin_amdgcn_wave_barrier();
         }
-        const uint64_t live = __ballot(active);
+        const uint64_t live = ballot64(active != 0u);
         if (!live) {
-            if (!more) break;
+            if (bcur == bend && chunk >= nchunks) break;
             continue;
         }
-        const bool at_leaf = active && (node & 0x80000000u);
-        const bool leaf_step = 2 * __popcll(__ballot(at_leaf)) > __popcll(live);
+        AO_STAT(0, 1), AO_STAT(1, __popcll(live));
+        const bool at_node = active && !(node & 0x80000000u) && node != kNoNode;
+        const bool waits = active && !at_node; // stands at a leaf with another set aside, or has only that one left
+        const bool leaf_step = 8u * (uint32_t)__popcll(ballot64(waits)) > (uint32_t)kAoLeafNum * (uint32_t)__popcll(live);
         bool ended = false, hit = false;
+        if (leaf_step)
+            AO_STAT(2, 1), AO_STAT(3, __popcll(ballot64(kAoPend ? (active && pend) : waits)));
+        else
+            AO_STAT(4, 1), AO_STAT(5, __popcll(ballot64(at_node)));
         if (leaf_step) {
-            if (at_leaf) {
-                const uint32_t k = node & 0x7FFFFFFFu;
-                if (mt_any(f, ox, oy, oz, wx, wy, wz, ao.tmax, TA[k], TB[k], TC[k]))
-                    hit = true, ended = true;
-                else if (sp == 0)
-                    ended = true;
-                else
-                    node = stack[(size_t)(--sp) * 256];
+            if (kAoPend ? (active && pend) : waits) {
+                const uint32_t k = (kAoPend ? pend : node) & 0x7FFFFFFFu;
+                if (mt_any(f, ox, oy, oz, wx, wy, wz, ao.tmax, TA[k], TB[k], TC[k])) hit = true, ended = true;
+                pend = 0;
+                if (!kAoPend) node = sp ? unpacked(stack[(size_t)(--sp) * 256]) : kNoNode;
             }
-        } else if (active && !at_leaf) {
-            const float4 q0 = nodes[4 * (size_t)node + 0], q1 = nodes[4 * (size_t)node + 1];
-            const float4 q2 = nodes[4 * (size_t)node + 2], q3 = nodes[4 * (size_t)node + 3];
-            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        } else if (at_node) {
+            const uint4 a0 = qnodes[2 * (size_t)node], a1 = qnodes[2 * (size_t)node + 1];
+            const uint32_t c0 = a0.w, c1 = a1.w;
             float tn0, tn1;
-            const bool h0 = slab_folded(rs, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlim, tn0);
-            const bool h1 = slab_folded(rs, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlim, tn1);
+            // (packed multiply-adds for the twelve plane terms were slower: 2.03 against 1.93 ms for the close-up)
+            const bool h0 = slab_folded(rs, (float)(a0.x & 0xFFFFu), (float)(a0.x >> 16), (float)(a0.y & 0xFFFFu),
+                                        (float)(a0.y >> 16), (float)(a0.z & 0xFFFFu), (float)(a0.z >> 16), tlim, tn0);
+            const bool h1 = slab_folded(rs, (float)(a1.x & 0xFFFFu), (float)(a1.x >> 16), (float)(a1.y & 0xFFFFu),
+                                        (float)(a1.y >> 16), (float)(a1.z & 0xFFFFu), (float)(a1.z >> 16), tlim, tn1);
             if (h0 && h1) { // nearer child first: an occluder close to the surface ends the ray soonest
                 const bool first1 = tn1 < tn0;
-                stack[(size_t)sp * 256] = first1 ? c0 : c1;
+                stack[(size_t)sp * 256] = packed(first1 ? c0 : c1);
                 sp++;
                 node = first1 ? c1 : c0;
             } else if (h0) {
@@ -1907,17 +1972,30 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
             } else if (h1) {
                 node = c1;
             } else if (sp == 0) {
-                ended = true;
+                node = kNoNode;
             } else {
-                node = stack[(size_t)(--sp) * 256];
+                node = unpacked(stack[(size_t)(--sp) * 256]);
             }
+        }
+        if (active && !ended) {
+            if (kAoPend && (node & 0x80000000u) && pend == 0) { // a leaf, and none set aside yet: set it aside and go on
+                pend = node;
+                node = sp ? unpacked(stack[(size_t)(--sp) * 256]) : kNoNode;
+            }
+            if (node == kNoNode && pend == 0) ended = true;
         }
         if (ended) {
             // the result is not read back here, so the wave does not wait for the atomic
             if (hit) __hip_atomic_fetch_add(&ao.acc[rec], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            active = false;
+            active = 0u;
+            AO_STAT(8, 1);
         }
     }
+#ifdef INV_AO_STATS
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_ao_stats[i], st[i]);
+    atomicAdd(&g_ao_stats[8], st[8]);
+#endif
 }
 
 // After the ray stream: one lane per queued pixel turns its occlusion count into the stored colour.
@@ -2165,12 +2243,26 @@ hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, cons
         return hipGetLastError();
     }
     const uint32_t entries = std::min<uint32_t>(sc.height + 1u, (uint32_t)kStack + 1u);
-    const size_t lds = (size_t)entries * 256u * sizeof(uint32_t);
+    const bool small = sc.ntri < 32768u; // child references fit 16 bits
+    const size_t lds = (size_t)entries * 256u * (small ? 2u : 4u) + 4u * kAoRayWords * 64u * sizeof(uint32_t);
     // as many workgroups as stay resident at once: 256 CUs x what the stack's LDS share allows (at most 8)
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / (lds + 512u)));
-    hipLaunchKernelGGL(k_ao, dim3(256u * per_cu), dim3(256), lds, s, f, ao, (const float4*)sc.triA,
-                       (const float4*)sc.triB, (const float4*)sc.triC, (const float4*)sc.nodes, out);
+    if (small)
+        hipLaunchKernelGGL(k_ao<uint16_t>, dim3(256u * per_cu), dim3(256), lds, s, f, ao, (const float4*)sc.triA,
+                           (const float4*)sc.triB, (const float4*)sc.triC, (const uint4*)sc.qnodes, qgrid_for(sc.bbox), out);
+    else
+        hipLaunchKernelGGL(k_ao<uint32_t>, dim3(256u * per_cu), dim3(256), lds, s, f, ao, (const float4*)sc.triA,
+                           (const float4*)sc.triB, (const float4*)sc.triC, (const uint4*)sc.qnodes, qgrid_for(sc.bbox), out);
     if (out.color) hipLaunchKernelGGL(k_ao_resolve, dim3(512), dim3(256), 0, s, f, ao, out);
     return hipGetLastError();
 }
 } // namespace inv
+
+#ifdef INV_AO_STATS
+// measurement builds only (tools/ao_stats.py): the counters of the occlusion kernel since the last call
+extern "C" int inv_debug_ao_stats(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(inv::g_ao_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(inv::g_ao_stats), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
