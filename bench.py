@@ -573,8 +573,10 @@ def main():
                        "rays_per_frame": rays_per_frame, "frames_per_step": args.frames_per_step,
                        "us_per_frame": elapsed / nframes * 1e6, "flags": int(flags),
                        "triangles": ntri, "lbvh_nodes": nnodes, "instances": side * side,
-                       # how a frame of this workload drawn on its own is traced (frames that share a launch: 16x16 blocks)
-                       "draw_path": path_names[path & 15] + (" after a binning pass" if path & R.api.PATH_BINNED else ""),
+                       # how the timed frames were traced: frames that share a launch go through 16x16 blocks, a frame
+                       # drawn on its own the way inv_draw_path says
+                       "draw_path": ("16x16 blocks, %d frames per launch" % fpl if kernel_name.startswith("k_render_tile_batch")
+                                     else path_names[path & 15] + (" after a binning pass" if path & R.api.PATH_BINNED else "")),
                        "bytes_read_per_frame": read_bytes,
                        # host wall of the scene build (upload, assembly, LBVH): first (with allocations) and last of three
                        "build_ms": [build_ms[0], build_ms[-1]], "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
