@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--brute-force", action="store_true", help="time the brute-force kernel instead of the LBVH one")
     ap.add_argument("--composite", default="sparse", choices=["sparse", "dense"],
                     help="N > 1: gather only the tiles that can contain hits (sparse) or the whole frame (dense)")
+    ap.add_argument("--root-share", default="auto", choices=["auto", "equal", "none"],
+                    help="N >= 3: rank 0 draws an equal share of the tiles, or none (INV_ROOT_IDLE: it alone writes the "
+                         "background and receives the tiles); auto: none from 4 ranks on for frames without occlusion rays")
     ap.add_argument("--gather", default="torch", choices=["torch", "c"],
                     help="N > 1, sparse composite: torch.distributed.gather, or the library's own exchange (inv_comm_gather: "
                          "grouped RCCL send / receive on the context's stream; staging files with --backend gloo)")
@@ -233,6 +236,8 @@ def main():
     cams = [R.camera_turntable(w, h, i / 60.0) for i in range(240)] if turntable else None  # one full turn
     ao_rays = wl.get("ao_rays", 0)
     sparse = world > 1 and args.composite == "sparse"
+    idle = world >= 3 and (args.root_share == "none" or (args.root_share == "auto" and world >= 4 and not ao_rays))
+    sflags = flags | (R.ROOT_IDLE if idle else 0)  # flags of the sharded draws
     gathered = frame = sc = None
     # frames per submission: occlusion rays and many samples per pixel are drawn frame by frame anyway
     fpl = args.frames_per_launch if world == 1 and not ao_rays and spp < 4 and side == 1 else 1
@@ -246,17 +251,19 @@ def main():
     direct = args.backend == "nccl" or comm is not None  # the composite's own exchange moves the tiles
     if grouped:
         fpl = args.composite_frames
-        cb = RD.SparseCompositeBatch(scene, cam, w, h, rank, world, frames=fpl, sets=2, tile=tile, spp=spp, flags=flags,
+        cb = RD.SparseCompositeBatch(scene, cam, w, h, rank, world, frames=fpl, sets=2, tile=tile, spp=spp, flags=sflags,
                                      ao_rays=ao_rays, comm=comm)
         npix = cb.slot_elems if rank else w * h - (world - 1) * cb.slot_elems  # pixels per frame this rank writes
     elif sparse:
-        sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=flags, ao_rays=ao_rays, comm=comm)
+        sc = RD.SparseComposite(scene, cam, w, h, rank, world, tile=tile, spp=spp, flags=sflags, ao_rays=ao_rays, comm=comm)
         frame, gathered = sc.frame, sc.gathered
         # pixels this rank's render launch writes
         npix = sc.slot_elems if rank else w * h - (world - 1) * sc.slot_elems
     else:
-        prm = R.make_params(w, h, spp=spp, flags=flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
+        prm = R.make_params(w, h, spp=spp, flags=sflags if world > 1 else flags, tile=tile, rank=rank, nranks=world, ao_rays=ao_rays)
         npix, _ = R.tile_layout(prm)
+        if world > 1 and npix == 0:  # rank 0 without tiles still brings a share of the gather's size
+            npix, _ = R.tile_layout(R.make_params(w, h, spp=spp, flags=sflags, tile=tile, rank=1, nranks=world, ao_rays=ao_rays))
         # attachments: one set (three planes: colour, depth, primitive id; 4 bytes per pixel each) per frame in
         # flight, times `rotate`: every slot goes round `rotate` groups of sets, so that the job streams through
         # --attachment-gb of memory and no set is still in the Infinity Cache when it is drawn into again
@@ -269,7 +276,7 @@ def main():
         if world > 1 and rank == 0:
             gathered = torch.empty(world, 3, npix, dtype=torch.int32, device="cuda")
             frame = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
-        prm0 = R.make_params(w, h, tile=tile, nranks=world)
+        prm0 = R.make_params(w, h, tile=tile, nranks=world, flags=sflags & R.ROOT_IDLE)
 
     # Render-kernel duration: with one GPU two HIP events per stream bracket that stream's launches of the timed
     # region (a stream holds nothing else, so their distance / launches is the average launch-to-launch time of
@@ -470,56 +477,63 @@ def main():
             ecam = R.camera_reference(ew, eh)
             if "view_translation" in xw:
                 ecam.view[12], ecam.view[13], ecam.view[14] = xw["view_translation"]
-            kw = dict(spp=xw["spp"], flags=xw["flags"], ao_rays=xw.get("ao_rays", 0))
-            esc = RD.SparseComposite(scene, ecam, ew, eh, rank, world, tile=32, comm=comm, **kw)
+            for share, share_flag in [("equal", 0)] + ([("rank0_idle", R.ROOT_IDLE)] if world >= 3 else []):
+                kw = dict(spp=xw["spp"], flags=xw["flags"], ao_rays=xw.get("ao_rays", 0))
+                esc = RD.SparseComposite(scene, ecam, ew, eh, rank, world, tile=32, comm=comm,
+                                         **dict(kw, flags=kw["flags"] | share_flag))
 
-            def composite_once():
-                if direct:
-                    esc.composite()
-                elif esc.slot_elems:  # rehearsal: the collective runs on host copies
-                    stream.synchronize()
-                    host = RD.gather_to_rank0(esc.planes.cpu(), rank, world)
+                def composite_once():
+                    if direct:
+                        esc.composite()
+                    elif esc.slot_elems:  # rehearsal: the collective runs on host copies
+                        stream.synchronize()
+                        host = RD.gather_to_rank0(esc.planes.cpu(), rank, world)
+                        if rank == 0:
+                            esc.gathered.copy_(host)
+                        esc.scatter_received()
+
+                def timed(body, n):
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t_0 = time.perf_counter()
+                    for _ in range(n):
+                        body()
+                    torch.cuda.synchronize()
+                    tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    return float(tt[0]) / n * 1e3
+
+                def both():
+                    esc.render()
+                    composite_once()
+
+                rehearsal = args.backend != "nccl"  # ranks sharing one GPU: enough frames to see that it works
+                for _ in range(1 if rehearsal else 3):
+                    both()
+                n_x = 4 if rehearsal else 20
+                render_ms = timed(esc.render, n_x)
+                both_ms = timed(both, n_x)
+                one = torch.empty(3, eh * ew, dtype=torch.int32, device="cuda") if rank == 0 else None
+                eprm = R.make_params(ew, eh, **kw)
+
+                def alone():
                     if rank == 0:
-                        esc.gathered.copy_(host)
-                    esc.scatter_received()
+                        scene.render_device(ecam, eprm, one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr())
 
-            def timed(body, n):
-                torch.cuda.synchronize()
-                dist.barrier()
-                t_0 = time.perf_counter()
-                for _ in range(n):
-                    body()
-                torch.cuda.synchronize()
-                tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                return float(tt[0]) / n * 1e3
-
-            def both():
-                esc.render()
-                composite_once()
-
-            for _ in range(3):
+                alone()
+                one_ms = timed(alone, n_x)
                 both()
-            n_x = 20
-            render_ms = timed(esc.render, n_x)
-            both_ms = timed(both, n_x)
-            one = torch.empty(3, eh * ew, dtype=torch.int32, device="cuda") if rank == 0 else None
-            eprm = R.make_params(ew, eh, **kw)
-
-            def alone():
-                if rank == 0:
-                    scene.render_device(ecam, eprm, one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr())
-
-            alone()
-            one_ms = timed(alone, n_x)
-            both()
-            torch.cuda.synchronize()
-            ok = bool(torch.equal(one, esc.frame)) if rank == 0 else True
-            extra[name] = {"render_only_ms": render_ms, "render_plus_gather_ms": both_ms, "one_gpu_ms": one_ms,
-                           "composite_equals_one_gpu_frame": ok, "frames_timed": n_x}
-            if rank == 0 and not ok:
-                raise SystemExit("extra workload %s: the composite differs from the single-GPU frame" % name)
-            del esc, one
+                torch.cuda.synchronize()
+                ok = bool(torch.equal(one, esc.frame)) if rank == 0 else True
+                res = {"render_only_ms": render_ms, "render_plus_gather_ms": both_ms, "one_gpu_ms": one_ms,
+                       "composite_equals_one_gpu_frame": ok, "frames_timed": n_x}
+                if rank == 0 and not ok:
+                    raise SystemExit("extra workload %s (%s): the composite differs from the single-GPU frame" % (name, share))
+                if share == "equal":
+                    extra[name] = res
+                else:  # the same with rank 0 drawing no tiles
+                    extra[name][share] = {k: res[k] for k in ("render_only_ms", "render_plus_gather_ms", "composite_equals_one_gpu_frame")}
+                del esc, one
 
     if world > 1 and rank == 0:
         # the composite must equal the same frame rendered by this rank alone
@@ -581,7 +595,7 @@ def main():
                        # host wall of the scene build (upload, assembly, LBVH): first (with allocations) and last of three
                        "build_ms": [build_ms[0], build_ms[-1]], "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,
                        "parallelism": ("%s tiles %% %d + RCCL gather to rank 0%s" % (
-                                           args.composite, world, (", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
+                                           args.composite, world, (", rank 0 draws no tiles" if idle else "") + (", %d frames per gather, 2 buffer sets" % fpl if grouped else "")
                                            + (", exchange through inv_comm_gather" if comm is not None else ""))
                                        if world > 1 else "1 GPU")},
             # `achieved` = algorithmic bytes of the frames drawn / wall time of the timed region: launches of different

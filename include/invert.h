@@ -52,6 +52,7 @@ enum {
     INV_BRUTE_FORCE = 8u, /* test every triangle for every ray instead of traversing the LBVH */
     INV_LANE_TRAVERSAL = 16u, /* one lane per ray with a stack in LDS instead of the tile kernel's candidate lists */
     INV_SPARSE = 32u,     /* with nranks > 1: deal out only the tiles that can contain hits (see inv_sparse_layout) */
+    INV_ROOT_IDLE = 128u, /* with nranks >= 3: rank 0 takes no tiles (it alone writes the background of a sparse composite and receives everyone's tiles); tile id belongs to rank 1 + id % (nranks - 1).  Every rank of a frame passes the same flag */
     INV_BLOCKS = 64u,     /* trace 16x16 pixel blocks with a wave per quadrant, as inv_render_batch does, instead of 8x8 tiles whose waves share the candidates: less arithmetic, longer for a draw on its own, and slow where a block meets hundreds of triangles (its pixels then go through the per-lane traversal) */
 };
 
@@ -64,7 +65,7 @@ typedef struct inv_params {
     uint32_t flags;   /* INV_* */
     uint32_t seed;    /* jitter / AO hash seed */
     uint32_t tile;    /* tile edge in pixels (a multiple of 32) used to shard a frame over ranks; 0 is read as 64 */
-    uint32_t rank;    /* this context renders the tiles with tile_id % nranks == rank */
+    uint32_t rank;    /* this context renders the tiles with tile_id % nranks == rank (INV_ROOT_IDLE: see there) */
     uint32_t nranks;  /* 0 is read as 1 */
     float ao_tmax;    /* AO ray length; 0 = scene bounding-box diagonal */
 } inv_params;

@@ -30,6 +30,9 @@ struct FrameK {
     // (sparse).  Grid tile id belongs to rank id % nranks and is that rank's slot id / nranks.
     uint32_t tile, rank, nranks, tiles_x, tiles_y, ntiles, slots; // slots = tiles stored per rank
     uint32_t gx0, gy0;
+    // INV_ROOT_IDLE: `nranks` counts the ranks that tiles are dealt to (all but rank 0) and `rank` is this rank's place
+    // among them (rank 0 itself: a value no tile id maps to); rank k's buffer is the (k + first_rank)-th of a gather.
+    uint32_t first_rank;
     uint32_t rowmajor; // outputs are a row-major width * height frame (one rank, or rank 0 of a sparse composite);
                        // otherwise this rank's slots one after another, tile * tile pixels each
     uint64_t npix;                                       // pixels this launch covers

@@ -151,13 +151,21 @@ int fill_layout(const inv_params& p, FrameK* f) {
     f->nranks = p.nranks ? p.nranks : 1u;
     f->rank = p.rank;
     if (f->rank >= f->nranks) return fail(INV_ERR_ARG, "params: rank must be below nranks");
+    f->first_rank = 0;
+    bool idle_root = false; // this is rank 0 of a frame whose rank 0 takes no tiles
+    if (p.flags & INV_ROOT_IDLE) {
+        if (f->nranks < 3u) return fail(INV_ERR_ARG, "params: INV_ROOT_IDLE needs at least three ranks");
+        idle_root = f->rank == 0;
+        f->first_rank = 1, f->nranks -= 1u;
+        f->rank = idle_root ? 0xFFFFFFFFu : f->rank - 1u;
+    }
     if (f->tile > 1024u || (f->tile & 31u)) return fail(INV_ERR_ARG, "params: tile must be a multiple of 32, at most 1024");
     f->tiles_x = (p.width + f->tile - 1) / f->tile;
     f->tiles_y = (p.height + f->tile - 1) / f->tile;
     f->gx0 = f->gy0 = 0;
     f->ntiles = f->tiles_x * f->tiles_y;
-    f->slots = (f->ntiles + f->nranks - 1) / f->nranks;
-    f->rowmajor = f->nranks == 1;
+    f->slots = idle_root ? 0u : (f->ntiles + f->nranks - 1) / f->nranks;
+    f->rowmajor = f->nranks == 1 && !f->first_rank;
     f->npix = f->rowmajor ? (uint64_t)p.width * p.height : (uint64_t)f->slots * f->tile * f->tile;
     return INV_OK;
 }
@@ -165,7 +173,7 @@ int fill_layout(const inv_params& p, FrameK* f) {
 // Sparse sharding (INV_SPARSE with several ranks): only the tiles the hit rectangle touches are dealt out; rank 0
 // holds the row-major frame and clears everything else itself.
 void apply_sparse_grid(const uint32_t rect[4], FrameK* f) {
-    if (f->nranks <= 1) return;
+    if (f->nranks + f->first_rank <= 1) return;
     const uint32_t T = f->tile;
     if (rect[2] > rect[0] && rect[3] > rect[1]) {
         f->gx0 = rect[0] / T, f->gy0 = rect[1] / T;
@@ -175,8 +183,9 @@ void apply_sparse_grid(const uint32_t rect[4], FrameK* f) {
         f->gx0 = f->gy0 = f->tiles_x = f->tiles_y = 0;
     }
     f->ntiles = f->tiles_x * f->tiles_y;
-    f->slots = (f->ntiles + f->nranks - 1) / f->nranks;
-    f->rowmajor = f->rank == 0;
+    const bool root = f->first_rank ? f->rank == 0xFFFFFFFFu : f->rank == 0;
+    f->slots = (f->ntiles + f->nranks - 1) / f->nranks; // (an idle rank 0 keeps the others' slot count: it sizes the gather)
+    f->rowmajor = root;
     f->npix = f->rowmajor ? (uint64_t)f->w * f->h : (uint64_t)f->slots * T * T;
 }
 
@@ -621,7 +630,7 @@ int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_param
     {
         // Bits above the INV_* flags switch parts of the kernels off for timing experiments (tools/phase_timing.py,
         // tools/tile_stats.py) and make the images wrong: they are refused unless INV_TIMING_SWITCHES is set.
-        constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE | INV_BLOCKS;
+        constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE | INV_BLOCKS | INV_ROOT_IDLE;
 #ifdef INV_TIMING_BUILD
         static const bool allow = std::getenv("INV_TIMING_SWITCHES") != nullptr;
 #else
@@ -934,9 +943,9 @@ int inv_tile_layout(const inv_params* params, uint64_t* npixels, uint32_t* tile_
     if (npixels) *npixels = f.npix;
     uint32_t count = 0;
     for (uint32_t slot = 0; slot < f.slots; slot++) {
-        uint32_t id = slot * f.nranks + f.rank;
+        uint64_t id = (uint64_t)slot * f.nranks + f.rank;
         if (id >= f.ntiles) break;
-        if (tile_ids && count < tile_ids_cap) tile_ids[count] = id;
+        if (tile_ids && count < tile_ids_cap) tile_ids[count] = (uint32_t)id;
         count++;
     }
     if (ntiles) *ntiles = count;
@@ -968,14 +977,14 @@ int inv_sparse_layout(const inv_params* params, const uint32_t rect[4], uint32_t
     if (rc != INV_OK) return rc;
     if ((rc = check_rect(rect, f.w, f.h, "inv_sparse_layout")) != INV_OK) return rc;
     const uint32_t frame_tiles_x = f.tiles_x;
-    if (f.nranks <= 1) return fail(INV_ERR_ARG, "inv_sparse_layout: the sparse composite needs at least two ranks");
+    if (f.nranks + f.first_rank <= 1) return fail(INV_ERR_ARG, "inv_sparse_layout: the sparse composite needs at least two ranks");
     apply_sparse_grid(rect, &f);
     if (grid) grid[0] = f.gx0, grid[1] = f.gy0, grid[2] = f.tiles_x, grid[3] = f.tiles_y;
     if (npixels) *npixels = f.npix;
     uint32_t count = 0;
-    for (uint32_t id = f.rank; id < f.ntiles; id += f.nranks) {
+    for (uint64_t id = f.rank; id < f.ntiles; id += f.nranks) { // (an idle rank 0 has rank 0xFFFFFFFF here: no tiles)
         if (tile_ids && count < tile_ids_cap)
-            tile_ids[count] = (f.gy0 + id / f.tiles_x) * frame_tiles_x + f.gx0 + id % f.tiles_x;
+            tile_ids[count] = (f.gy0 + (uint32_t)id / f.tiles_x) * frame_tiles_x + f.gx0 + (uint32_t)id % f.tiles_x;
         count++;
     }
     if (ntiles) *ntiles = count;
@@ -993,7 +1002,7 @@ int inv_deinterleave_sparse(inv_ctx* ctx, const inv_params* params, const uint32
     int rc = fill_layout(p, &f);
     if (rc != INV_OK) return rc;
     if ((rc = check_rect(rect, f.w, f.h, "inv_deinterleave_sparse")) != INV_OK) return rc;
-    if (f.nranks <= 1) return fail(INV_ERR_ARG, "inv_deinterleave_sparse: the sparse composite needs at least two ranks");
+    if (f.nranks + f.first_rank <= 1) return fail(INV_ERR_ARG, "inv_deinterleave_sparse: the sparse composite needs at least two ranks");
     apply_sparse_grid(rect, &f);
     if (f.ntiles == 0 || nplanes == 0) return INV_OK; // nothing was dealt out: rank 0 already holds the frame
     if (!gathered) return fail(INV_ERR_ARG, "inv_deinterleave_sparse: gathered is null");

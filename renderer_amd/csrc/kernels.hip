@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_deinterleave(FrameK f, const uint32_t* 
     if (i >= (uint64_t)f.w * f.h) return;
     uint32_t px = (uint32_t)(i % f.w), py = (uint32_t)(i / f.w);
     uint32_t id = (py / f.tile) * f.tiles_x + px / f.tile;
-    uint32_t r = id % f.nranks, slot = id / f.nranks;
+    uint32_t r = id % f.nranks + f.first_rank, slot = id / f.nranks;
     uint64_t src = (uint64_t)r * rank_stride + (uint64_t)slot * (f.tile * f.tile) + (py % f.tile) * f.tile + px % f.tile;
     frame[i] = gathered[src];
 }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_deinterleave_sparse(FrameK f, const uin
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)f.ntiles * tt) return;
     const uint32_t id = (uint32_t)(i / tt), rem = (uint32_t)(i % tt);
-    const uint32_t r = id % f.nranks;
+    const uint32_t r = id % f.nranks + f.first_rank;
     if (r == 0) return;
     const uint32_t px = (f.gx0 + id % f.tiles_x) * f.tile + rem % f.tile;
     const uint32_t py = (f.gy0 + id / f.tiles_x) * f.tile + rem / f.tile;

@@ -66,6 +66,9 @@ def shard_params(width, height, rank, world, tile=64, **kw) -> api.Params:
 def alloc_planes(prm: api.Params, device) -> torch.Tensor:
     """[3, npix] int32: colour, depth bits and primitive id of this rank's tile slots (4 bytes per pixel each)."""
     npix, _ = api.tile_layout(prm)
+    if npix == 0 and (prm.flags & api.ROOT_IDLE):  # an idle rank 0 draws nothing, but a gather wants equal shares
+        other = api.make_params(prm.width, prm.height, tile=prm.tile, rank=1, nranks=prm.nranks, flags=prm.flags)
+        npix, _ = api.tile_layout(other)
     return torch.empty(3, npix, dtype=torch.int32, device=device)
 
 

@@ -125,7 +125,7 @@ def dense_composite_single_gpu(scene, ctx, cam, w, h, nranks, tile, **kw):
 
     import renderer_amd as R
     prm = [R.make_params(w, h, tile=tile, rank=r, nranks=nranks, **kw) for r in range(nranks)]
-    npix, _ = R.tile_layout(prm[0])
+    npix, _ = R.tile_layout(prm[-1])  # (rank 0 holds nothing when it is idle)
     gathered = torch.full((nranks, 3, npix), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
     frame = torch.full((3, h * w), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
     for r in range(nranks):

@@ -217,6 +217,28 @@ def test_sparse_layout_deals_each_grid_tile_once():
             seen += [int(i) for i in ids]
         want = sorted((4 + ty) * 30 + 13 + tx for ty in range(4) for tx in range(4))
         assert sorted(seen) == want
+    # rank 0 idle: the same tiles dealt to ranks 1.., rank 0 keeps the frame and takes none
+    for world in (3, 4, 8):
+        seen = []
+        for r in range(world):
+            prm = R.make_params(w, h, tile=tile, rank=r, nranks=world, flags=R.SPARSE | R.ROOT_IDLE)
+            grid, npix, ids = R.sparse_layout(prm, rect)
+            assert grid == (13, 4, 4, 4)
+            assert npix == (w * h if r == 0 else -(-16 // (world - 1)) * tile * tile)
+            assert (len(ids) == 0) if r == 0 else all((int(i) // 30 - 4) * 4 + int(i) % 30 - 13 >= 0 for i in ids)
+            seen += [int(i) for i in ids]
+        assert sorted(seen) == want
+        # the dense layout: every tile of the frame to ranks 1.., none to rank 0
+        total = []
+        for r in range(world):
+            npix, ids = R.tile_layout(R.make_params(w, h, tile=tile, rank=r, nranks=world, flags=R.ROOT_IDLE))
+            assert npix == (0 if r == 0 else -(-510 // (world - 1)) * tile * tile)
+            assert r != 0 or len(ids) == 0
+            assert (ids % (world - 1) == r - 1).all()
+            total += list(ids)
+        assert sorted(total) == list(range(510))
+    with pytest.raises(R.InvertError):
+        R.tile_layout(R.make_params(w, h, rank=1, nranks=2, flags=R.ROOT_IDLE))  # needs a rank beside rank 0 to share with
     # an empty rectangle deals nothing
     grid, npix, ids = R.sparse_layout(R.make_params(w, h, rank=1, nranks=2, flags=R.SPARSE), (0, 0, 0, 0))
     assert grid[2] * grid[3] == 0 and npix == 0 and len(ids) == 0

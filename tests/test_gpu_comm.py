@@ -29,7 +29,8 @@ def _read(prefix, w, h):
     return rgb, depth, primid
 
 
-@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--ao", "16"]), (4, ["--spp", "4", "--turntable"])])
+@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--ao", "16"]), (4, ["--spp", "4", "--turntable"]),
+                                         (4, ["--rank0-idle"])])
 def test_headless_ranks_over_the_host_transport(bunny_path, tmp_path, ranks, extra):
     """N processes of the C++ host program share this GPU: each draws its tiles, inv_comm_gather carries the slot
     buffers to rank 0 through files, rank 0's frame equals the frame of a single process."""
@@ -38,7 +39,8 @@ def test_headless_ranks_over_the_host_transport(bunny_path, tmp_path, ranks, ext
     w, h = 1280, 720
     common = [EXE, "--obj", bunny_path, "--width", str(w), "--height", str(h), "--lambert", "--invert", "--frames", "3", *extra]
     single = str(tmp_path / "single")
-    p = subprocess.run(common + ["--in-flight", "1", "--per-launch", "1", "--out", single], capture_output=True, text=True, timeout=100)
+    alone = [a for a in common if a != "--rank0-idle"]  # (a flag of sharded frames only)
+    p = subprocess.run(alone + ["--in-flight", "1", "--per-launch", "1", "--out", single], capture_output=True, text=True, timeout=100)
     assert p.returncode == 0, p.stdout + p.stderr
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as meet:
         out = str(tmp_path / "composite")
@@ -52,7 +54,8 @@ def test_headless_ranks_over_the_host_transport(bunny_path, tmp_path, ranks, ext
             results.append(json.loads(so.strip().splitlines()[-1]))
         assert os.listdir(meet) == []  # every staging file was consumed
     assert [r["rank"] for r in results] == list(range(ranks)) and all(r["transport"] == "host" for r in results)
-    assert results[0]["tiles_dealt"] > ranks and results[0]["slot_elements"] == -(-results[0]["tiles_dealt"] // ranks) * 32 * 32
+    sharing = ranks - ("--rank0-idle" in extra)  # ranks that draw tiles
+    assert results[0]["tiles_dealt"] > ranks and results[0]["slot_elements"] == -(-results[0]["tiles_dealt"] // sharing) * 32 * 32
     got, want = _read(out, w, h), _read(single, w, h)
     for g, x in zip(got, want):
         assert np.array_equal(g.view(np.uint8), x.view(np.uint8))

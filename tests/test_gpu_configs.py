@@ -48,18 +48,20 @@ def test_config3_4k_16spp_against_oracle(bunny_scene, config3_frame):
     assert len(np.unique(got[0][hits][:, 0])) > 150
 
 
-@pytest.mark.parametrize("nranks", [2, 4, 8])
-def test_config3_sparse_shards_reassemble(bunny_scene, gpu_ctx, config3_frame, nranks):
+@pytest.mark.parametrize("nranks,idle", [(2, 0), (4, 0), (8, 0), (3, 1), (4, 1), (8, 1)])
+def test_config3_sparse_shards_reassemble(bunny_scene, gpu_ctx, config3_frame, nranks, idle):
+    """`idle`: rank 0 takes no tiles (INV_ROOT_IDLE), the hit tiles are dealt to the other ranks."""
     got, rect, grid, n = common.sparse_composite_single_gpu(bunny_scene, gpu_ctx, R.camera_reference(W4K, H4K), W4K, H4K,
-                                                            nranks, 32, spp=16, seed=0, flags=FLAGS)
+                                                            nranks, 32, spp=16, seed=0,
+                                                            flags=FLAGS | (R.ROOT_IDLE if idle else 0))
     common.assert_frames_equal(got, config3_frame, "config 3, sparse shards of %d ranks" % nranks)
-    assert n == -(-grid[2] * grid[3] // nranks) * 32 * 32
+    assert n == -(-grid[2] * grid[3] // (nranks - idle)) * 32 * 32
 
 
-@pytest.mark.parametrize("nranks", [2, 4, 8])
-def test_config3_dense_shards_reassemble(bunny_scene, gpu_ctx, config3_frame, nranks):
+@pytest.mark.parametrize("nranks,idle", [(2, 0), (4, 0), (8, 0), (4, 1)])
+def test_config3_dense_shards_reassemble(bunny_scene, gpu_ctx, config3_frame, nranks, idle):
     got = common.dense_composite_single_gpu(bunny_scene, gpu_ctx, R.camera_reference(W4K, H4K), W4K, H4K, nranks, 64,
-                                            spp=16, seed=0, flags=FLAGS)
+                                            spp=16, seed=0, flags=FLAGS | (R.ROOT_IDLE if idle else 0))
     common.assert_frames_equal(got, config3_frame, "config 3, dense shards of %d ranks" % nranks)
 
 

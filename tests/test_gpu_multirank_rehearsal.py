@@ -34,12 +34,19 @@ def _run(nranks, *extra, steps=3, warmup=1):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("nranks,extra", [(2, ()), (3, ("--workload", "bunny_1080p_ao64")), (2, ("--composite", "dense"))])
+@pytest.mark.parametrize("nranks,extra", [(2, ()), (3, ("--workload", "bunny_1080p_ao64")), (2, ("--composite", "dense")),
+                                          (3, ("--root-share", "none")), (4, ("--composite-frames", "1")),
+                                          (3, ("--composite", "dense", "--root-share", "none"))])
 def test_bench_with_several_ranks_on_one_gpu(nranks, extra):
     r = _run(nranks, *extra)
     assert r["n_gpus"] == nranks and r["steps"] == 3 and r["scaling"] == "strong"
     assert r["value"] > 0 and r["config"]["hit_pixels"] == 25139
     assert ("dense" if "dense" in extra else "sparse") in r["config"]["parallelism"]
+    # rank 0 draws no tiles when asked to, and by default from four ranks on
+    assert ("rank 0 draws no tiles" in r["config"]["parallelism"]) == ("none" in extra or nranks >= 4)
+    if nranks >= 3 and "dense" not in extra:  # the heavier workloads are timed with both shares
+        for x in r["extra_workloads"].values():
+            assert x["composite_equals_one_gpu_frame"] and x["rank0_idle"]["composite_equals_one_gpu_frame"]
 
 
 @pytest.mark.gpu

@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
         else if (a == "--lambert") flags |= INV_LAMBERT;
         else if (a == "--invert") flags |= INV_INVERT;
         else if (a == "--rgba") flags |= INV_RGBA;
+        else if (a == "--rank0-idle") flags |= INV_ROOT_IDLE; // several ranks: rank 0 draws no tiles
         else if (a == "--width") ok = value(&width);
         else if (a == "--height") ok = value(&height);
         else if (a == "--spp") ok = value(&spp);
