@@ -436,8 +436,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                                            const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                            const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
                                            uint32_t ncut, uint32_t* __restrict__ bin_count,
-                                           const uint2* __restrict__ bin_list, uint32_t ntri, int vec4, const AoK& ao,
-                                           const Outputs& out) {
+                                           const uint2* __restrict__ bin_list, const float4* __restrict__ flat,
+                                           uint32_t nflat, uint32_t ntri, int vec4, const AoK& ao, const Outputs& out) {
     constexpr uint32_t NT = NW * 64;
     static_assert(NT == (uint32_t)kRangeCap, "one lane per entry of a bin");
 #ifndef INV_PACK_TILES
@@ -478,12 +478,44 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     //      records, then the records of the surviving groups, one box per lane; whatever is still a subtree after
     //      that is opened breadth-first ----
     // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
-    const uint32_t ngroups = bin_count ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
+    // ---- phase 1, flat (small scenes): the first two fine-cut records of this lane are fetched before anything else
+    const bool flat_mode = !bin_count && nflat != 0u; // block-uniform
+    float4 fl_lo[2], fl_hi[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        fl_lo[u] = fl_hi[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t q = (uint32_t)u * NT + tid;
+        if (flat_mode && q < nflat) fl_lo[u] = flat[2 * (size_t)q], fl_hi[u] = flat[2 * (size_t)q + 1];
+    }
+    const uint32_t ngroups = bin_count || flat_mode ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
     float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
     if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
     if (!bin_count) {
         if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.rec_overflow = 0, S.n_groups = 0;
         __syncthreads();
+    }
+    if (flat_mode) {
+        for (uint32_t base = 0; base < nflat; base += 2u * NT) { // block-uniform trip count: one trip up to 512 records
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t q = base + (uint32_t)u * NT + tid;
+                if (base + (uint32_t)u * NT >= nflat) break; // block-uniform
+                bool in = false;
+                uint32_t first = 0, count = 0;
+                if (q < nflat) {
+                    const float4 lo = base ? flat[2 * (size_t)q] : fl_lo[u], hi = base ? flat[2 * (size_t)q + 1] : fl_hi[u];
+                    first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
+                    in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+                }
+                const uint32_t ar = wave_append(&S.n_ranges, in, lane);
+                if (in) {
+                    if (ar < (uint32_t)kRangeCap)
+                        S.u.t.ranges[ar] = make_uint2(first, count);
+                    else
+                        S.overflow = 1;
+                }
+            }
+        }
     }
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
         const uint32_t g = base + tid;
@@ -596,7 +628,7 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     const uint32_t nranges = S.n_ranges;
     // lanes per range: a bin's ranges are records of the fine cut (at most kFineMax leaves), the coarse cut's have up
     // to kRangeMax
-    const uint32_t rshift = bin_count ? (uint32_t)__builtin_ctz(kFineMax) : (uint32_t)__builtin_ctz(kRangeMax);
+    const uint32_t rshift = bin_count || flat_mode ? (uint32_t)__builtin_ctz(kFineMax) : (uint32_t)__builtin_ctz(kRangeMax);
     // the triangles of ranges [r0, r1) that can cover a sample of the tile -> S.u.t.rec (arguments block-uniform)
     const auto build_records = [&](uint32_t r0, uint32_t r1) {
         // directions through the four corners of the grown tile (for the facing test)
@@ -881,7 +913,8 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
                                             const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                             const float4* __restrict__ cut, const float4* __restrict__ cut_groups,
                                             uint32_t ncut, uint32_t* __restrict__ bin_count,
-                                            const uint2* __restrict__ bin_list, uint32_t ntri, int vec4, const AoK& ao,
+                                            const uint2* __restrict__ bin_list, const float4* __restrict__ flat,
+                                            uint32_t nflat, uint32_t ntri, int vec4, const AoK& ao,
                                             const Outputs& out) {
     constexpr uint32_t NT = 256;
     static_assert(NT == (uint32_t)kRangeCap, "one lane per entry of a bin");
@@ -914,12 +947,44 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
     //      records, then the records of the surviving groups, one box per lane; whatever is still a subtree after
     //      that is opened breadth-first ----
     // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
-    const uint32_t ngroups = bin_count ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
+    // ---- phase 1, flat (small scenes): the first two fine-cut records of this lane are fetched before anything else
+    const bool flat_mode = !bin_count && nflat != 0u; // block-uniform
+    float4 fl_lo[2], fl_hi[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        fl_lo[u] = fl_hi[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t q = (uint32_t)u * NT + tid;
+        if (flat_mode && q < nflat) fl_lo[u] = flat[2 * (size_t)q], fl_hi[u] = flat[2 * (size_t)q + 1];
+    }
+    const uint32_t ngroups = bin_count || flat_mode ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
     float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
     if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
     if (!bin_count) {
         if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
         __syncthreads();
+    }
+    if (flat_mode) {
+        for (uint32_t base = 0; base < nflat; base += 2u * NT) { // block-uniform trip count: one trip up to 512 records
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t q = base + (uint32_t)u * NT + tid;
+                if (base + (uint32_t)u * NT >= nflat) break; // block-uniform
+                bool in = false;
+                uint32_t first = 0, count = 0;
+                if (q < nflat) {
+                    const float4 lo = base ? flat[2 * (size_t)q] : fl_lo[u], hi = base ? flat[2 * (size_t)q + 1] : fl_hi[u];
+                    first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
+                    in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+                }
+                const uint32_t ar = wave_append(&S.n_ranges, in, lane);
+                if (in) {
+                    if (ar < (uint32_t)kRangeCap)
+                        S.u.t.ranges[ar] = make_uint2(first, count);
+                    else
+                        S.overflow = 1;
+                }
+            }
+        }
     }
     if (stamps) ta = __builtin_amdgcn_s_memtime();
     for (uint32_t base = 0; base < ngroups; base += NT) { // block-uniform trip count
@@ -1061,7 +1126,7 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
         dabs = dabs + dabs;
         // lanes per range: a bin's ranges are records of the fine cut (at most kFineMax leaves), the coarse cut's
         // have up to kRangeMax
-        const uint32_t rshift = bin_count ? (uint32_t)__builtin_ctz(kFineMax) : (uint32_t)__builtin_ctz(kRangeMax);
+        const uint32_t rshift = bin_count || flat_mode ? (uint32_t)__builtin_ctz(kFineMax) : (uint32_t)__builtin_ctz(kRangeMax);
         const uint32_t nslots = nranges << rshift;
         for (uint32_t base = 0; base < nslots; base += 2u * NT) { // block-uniform trip count; two triangles per lane
             float4 A[2], B[2], C[2];                              // and trip, all loads in flight before the first test
@@ -1236,6 +1301,11 @@ struct TilePlan {
     uint32_t* bin_count;
     uint2* bin_list;
     uint32_t ntri;              // triangles of the scene: no list entry is followed past the arrays
+    // Scenes of a few hundred fine-cut records (flat != null, no bins): a block tests every record against its own
+    // frustum, two or four per lane, instead of walking the coarse cut's two levels: its first list of leaf ranges
+    // is one round trip away instead of two.
+    const float4* flat;
+    uint32_t nflat;
 };
 
 // How a frame's traced rectangle is worked through (chosen per frame by plan_tile_frame):
@@ -1277,9 +1347,11 @@ __device__ __forceinline__ void tile_block(const FrameK& f, const TilePlan& pl, 
     uint32_t* const bin_count = pl.bin_count ? pl.bin_count + tb : nullptr;
     const uint2* const bin_list = pl.bin_list + (size_t)tb * (uint32_t)kRangeCap;
     if constexpr (MODE == kBlocks)
-        trace_block(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, bin_count, bin_list, pl.ntri, pl.vec4, ao, out);
+        trace_block(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, bin_count, bin_list, pl.flat, pl.nflat, pl.ntri,
+                    pl.vec4, ao, out);
     else
-        trace_tile<4, MODE == kBatched>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, bin_count, bin_list, pl.ntri, pl.vec4, ao, out);
+        trace_tile<4, MODE == kBatched>(f, S, tx0, ty0, TA, TB, TC, nodes, cut, cut_groups, ncut, bin_count, bin_list, pl.flat,
+                                        pl.nflat, pl.ntri, pl.vec4, ao, out);
 }
 
 // One workgroup of the fill part: block `fb` of pl.fill_blocks.  The fill blocks store the clear values of every
@@ -2012,10 +2084,24 @@ __global__ __launch_bounds__(256) void k_ao_resolve(FrameK f, AoK ao, Outputs ou
 
 } // namespace
 
+// Small scenes: blocks test the whole fine cut themselves (TilePlan::flat).  INV_FLAT=0 / 1 in the environment: never /
+// up to 2048 records (measurements); otherwise up to kFlatMax records.
+constexpr uint32_t kFlatMax = 1024;
+static bool flat_wanted(const DeviceScene& sc) {
+    static const int env = [] {
+        const char* e = std::getenv("INV_FLAT");
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    if (!sc.has_bvh || sc.nfine == 0 || env == 0) return false;
+    return sc.nfine <= (env == 1 ? 2048u : kFlatMax);
+}
+
 // Grid terms of one frame of the tile kernel and the way its traced rectangle is worked through.
 static TilePlan plan_tile_frame(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch, int* mode) {
     TilePlan pl;
     pl.bin_count = nullptr, pl.bin_list = nullptr, pl.ntri = sc.ntri;
+    pl.flat = nullptr, pl.nflat = 0;
+    if (flat_wanted(sc)) pl.flat = (const float4*)sc.fine, pl.nflat = sc.nfine;
     if (f.rowmajor)
         pl.pixel_blocks = ((f.w + 31u) >> 5) * ((f.h + 7u) >> 3);
     else

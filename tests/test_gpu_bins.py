@@ -106,3 +106,10 @@ def test_parity_suite_with_one_lane_per_triangle():
     drawn one lane per triangle into a visibility buffer (by default only frames whose triangles are far smaller than
     a pixel are), including shards of several ranks and frames with occlusion rays."""
     _parity_suite_with(INV_SCATTER="1")
+
+
+def test_parity_suite_from_the_coarse_cut():
+    """The parity tests again with INV_FLAT=0: blocks of small scenes walk the coarse cut's two levels, as blocks of
+    larger scenes do, instead of testing the whole fine cut themselves (the default up to 1024 records)."""
+    _parity_suite_with(INV_FLAT="0")
+
