@@ -1739,10 +1739,6 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
         }
         eps = pair_eps(f.ox, f.oy, f.oz, dabs + dabs, A, B, C);
     }
-#ifdef INV_SC_NOLOOP
-    if (eps == 12345.0f) vis[1] = 1ull;
-    return;
-#endif
     for (uint32_t py = y0; py <= y1; py++)
         for (uint32_t px = x0; px <= x1; px++) {
             float dx, dy, dz;
@@ -1760,11 +1756,7 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
             const Ray ray = make_ray(f, px, py, 0.5f, 0.5f);
             Hit best = miss_hit();
             mt_test(f, ray, A, B, C, k, best);
-#ifndef INV_SC_NOATOMIC
             if (best.key != kMissKey) atomicMin(&vis[(size_t)py * f.w + px], (unsigned long long)best.key);
-#else
-            if (best.key == 12345ull) vis[0] = best.key;
-#endif
         }
 }
 
