@@ -22,6 +22,7 @@ struct FrameK {
     float inv_p00, inv_p11;   // 1.0f / P00, 1.0f / P11, correctly rounded (div_by; also used by the culling)
     // approximate helpers for conservative culling only (never used for a pixel's value)
     float inv_w2, inv_h2;     // 2/width, 2/height
+    float dir_abs_max;        // bound on |component| of the object-space ray direction over the frame's hit rectangle
     uint32_t rx0, ry0, rx1, ry1; // pixel rectangle that can contain hits (projected scene bounds); rest is clear
     uint32_t w, h;
     uint32_t spp, flags, seed;

@@ -646,6 +646,21 @@ int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_param
     uint32_t rect[4] = {0, 0, f.w, f.h};
     if (scene->d.has_bvh) hit_rect(f, scene->d.bbox, rect);
     f.rx0 = rect[0], f.ry0 = rect[1], f.rx1 = rect[2], f.ry1 = rect[3];
+    {
+        // Bound on the components of the object-space ray direction over the hit rectangle (a pixel wider on every
+        // side): the direction is linear in the pixel position, so its components are largest at a corner.  The same
+        // float32 arithmetic as the kernels' dir_at, then a relative margin far above its roundings.
+        float worst = 0.0f;
+        for (int c = 0; c < 4; c++) {
+            const float x = (c & 1) ? (float)f.rx1 + 1.0f : (float)f.rx0 - 1.0f, y = (c & 2) ? (float)f.ry1 + 1.0f : (float)f.ry0 - 1.0f;
+            const float xn = x * f.inv_w2 - 1.0f, yn = y * f.inv_h2 - 1.0f;
+            const float dxv = xn * f.inv_p00, dyv = yn * f.inv_p11;
+            const float d[3] = {(f.d0x * dxv + f.d1x * dyv) - f.d2x, (f.d0y * dxv + f.d1y * dyv) - f.d2y,
+                                (f.d0z * dxv + f.d1z * dyv) - f.d2z};
+            for (float v : d) worst = std::max(worst, std::fabs(v));
+        }
+        f.dir_abs_max = worst * 1.0001f;
+    }
     if (f.flags & INV_SPARSE) apply_sparse_grid(rect, &f);
     return INV_OK;
 }

@@ -1676,88 +1676,149 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
 // rectangle that the eight corners of the box, grown by two pads, project to, widened by 1/8 pixel.  A box that
 // reaches the eye's plane tries every pixel of the frame's hit rectangle.
 // One sample per pixel only (frames with more take the tile kernel).
+#ifndef INV_SCATTER_PER_LANE
+#define INV_SCATTER_PER_LANE 2
+#endif
+constexpr uint32_t kScatterPerLane = INV_SCATTER_PER_LANE; // triangles per lane of the triangle pass
+constexpr uint32_t kPairCap = 1024; // (triangle, pixel) pairs a workgroup of the triangle pass lists before it tests them
+
+// The exact test of one (triangle, pixel) pair and the key minimum in the visibility buffer.
+__device__ __forceinline__ void scatter_pair(const FrameK& f, uint32_t k, uint32_t px, uint32_t py, const float4& A,
+                                             const float4& B, const float4& C, unsigned long long* __restrict__ vis) {
+    const Ray ray = make_ray(f, px, py, 0.5f, 0.5f);
+    Hit best = miss_hit();
+    mt_test(f, ray, A, B, C, k, best);
+    if (best.key != kMissKey) atomicMin(&vis[(size_t)py * f.w + px], (unsigned long long)best.key);
+}
+
+// Part one, a lane per triangle: the back-face test; the triangles that pass are listed in LDS.  Part two, a lane per
+// listed triangle (about half as many): the pixels its projection can cover and the cheap inside test on each of them;
+// what passes is listed as (triangle, pixel) pairs.  Part three, a lane per listed pair: the exact ray and the full
+// test.  (All in one loop per triangle, a wave ran the full test once per loop trip for whichever lanes had a
+// candidate in that trip, and everything behind the back-face test with half its lanes: 760 wave-instructions per
+// wave at 42 % of lanes.)
 __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float4* __restrict__ TA,
                                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                            uint32_t ntri, unsigned long long* __restrict__ vis) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= ntri) return;
-    const float4 A = TA[k], B = TB[k], C = TC[k];
-    // cull BACK (src/invert.cpp:1334).  For a ray from the origin o that meets the triangle's plane at p = o + t d,
-    // t > 0, det = e1 . (d x e2) = (p - o) . (e2 x e1) / t, and (p - o) . n is the same for every p of the plane: its
-    // sign at v0 decides for all rays at once.  The terms of the cheap inside test below carry it: det = d . P0 and
-    // o - v0 = t0, so the test is t0 . P0 >= 0 (clearly so: a margin of the products' rounding keeps the doubtful).
-    float4 P0, P1, P2;
-    fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
-    {
-        const float tx = f.ox - A.x, ty = f.oy - A.y, tz = f.oz - A.z;
-        const float s = (tx * P0.x + ty * P0.y) + tz * P0.z; // = -(v0 - o) . n: positive when the front faces the eye
-        const float mag = (fabsf(tx * P0.x) + fabsf(ty * P0.y)) + fabsf(tz * P0.z);
-        if (s > 1e-4f * mag) return; // det = -s / t < 0 for every ray
-    }
-    // the triangle's box exactly as the guard of mt_test forms it
-    const float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
-    const float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
-    const float grow = 2.0f * f.pad;
-    const float X[2] = {fminf(A.x, fminf(bx, cx)) - grow, fmaxf(A.x, fmaxf(bx, cx)) + grow};
-    const float Y[2] = {fminf(A.y, fminf(by, cy)) - grow, fmaxf(A.y, fmaxf(by, cy)) + grow};
-    const float Z[2] = {fminf(A.z, fminf(bz, cz)) - grow, fmaxf(A.z, fmaxf(bz, cz)) + grow};
-    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-    bool whole = false;
+    __shared__ uint32_t s_nfront, s_npairs;
+    __shared__ uint32_t s_front[256 * kScatterPerLane]; // the listed triangles, and their records (read once from memory)
+    __shared__ float4 s_recA[256 * kScatterPerLane], s_recB[256 * kScatterPerLane], s_recC[256 * kScatterPerLane];
+    __shared__ uint2 s_pairs[kPairCap]; // (place in the list, px | py << 16)
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x == 0) s_nfront = 0, s_npairs = 0;
+    __syncthreads();
+    // kScatterPerLane triangles per lane, their records all in flight before the first is looked at: a workgroup is a
+    // chain of three memory round trips whatever it holds, so it should hold enough to keep the memory system busy
+    float4 rA[kScatterPerLane], rB[kScatterPerLane], rC[kScatterPerLane];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const float x = X[c & 1], y = Y[(c >> 1) & 1], z = Z[c >> 2];
-        const float xv = (f.mv[0] * x + f.mv[1] * y) + (f.mv[2] * z + f.mv[3]);
-        const float yv = (f.mv[4] * x + f.mv[5] * y) + (f.mv[6] * z + f.mv[7]);
-        const float zv = (f.mv[8] * x + f.mv[9] * y) + (f.mv[10] * z + f.mv[11]);
-        const float w = -zv; // w_clip of a GLM perspective
-        const float rw = 1.0f / w;
-        const float fx = ((f.p00 * xv) * rw + 1.0f) * (0.5f * f.wf);
-        const float fy = ((f.p11 * yv) * rw + 1.0f) * (0.5f * f.hf);
-        whole = whole || !(w > 1e-30f) || !(fx == fx) || !(fy == fy);
-        xmin = fminf(xmin, fx), xmax = fmaxf(xmax, fx), ymin = fminf(ymin, fy), ymax = fmaxf(ymax, fy);
+    for (uint32_t u = 0; u < kScatterPerLane; u++) {
+        const uint32_t k = (blockIdx.x * kScatterPerLane + u) * 256u + threadIdx.x;
+        rA[u] = rB[u] = rC[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k < ntri) rA[u] = TA[k], rB[u] = TB[k], rC[u] = TC[k];
     }
-    // pixel centres px + 0.5 inside [xmin - m, xmax + m], clipped to the rectangle that can contain hits
-    const float m = 0.125f;
-    float fx0 = ceilf(xmin - m - 0.5f), fx1 = floorf(xmax + m - 0.5f);
-    float fy0 = ceilf(ymin - m - 0.5f), fy1 = floorf(ymax + m - 0.5f);
-    if (whole) fx0 = 0.0f, fy0 = 0.0f, fx1 = f.wf, fy1 = f.hf;
-    if (!(fx1 >= (float)f.rx0 && fy1 >= (float)f.ry0 && fx0 <= (float)f.rx1 - 1.0f && fy0 <= (float)f.ry1 - 1.0f)) return;
-    const uint32_t x0 = (uint32_t)fmaxf(fx0, (float)f.rx0), y0 = (uint32_t)fmaxf(fy0, (float)f.ry0);
-    const uint32_t x1 = (uint32_t)fminf(fx1, (float)f.rx1 - 1.0f), y1 = (uint32_t)fminf(fy1, (float)f.ry1 - 1.0f);
-    if (x0 > x1 || y0 > y1) return;
-    // The cheap inside test of the tile kernel (mt_inside_pair, one record): the three dot products of the folded
-    // terms with the pixel's direction, every comparison widened by a bound on the roundings (of these products, of
-    // mt_test's own, and of the reciprocal multiplies in dir_at).  Only pixels it lets through get their exact ray
-    // and the full test, which alone decides.
-    float eps;
-    {
-        float cdx[4], cdy[4], cdz[4], dabs = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            dir_at(f, (c & 1) ? (float)x1 + 1.0f : (float)x0, (c & 2) ? (float)y1 + 1.0f : (float)y0, cdx[c], cdy[c], cdz[c]);
-            dabs = fmaxf(dabs, fmaxf(fmaxf(fabsf(cdx[c]), fabsf(cdy[c])), fabsf(cdz[c])));
+    for (uint32_t u = 0; u < kScatterPerLane; u++) {
+        const uint32_t k = (blockIdx.x * kScatterPerLane + u) * 256u + threadIdx.x;
+        bool front = false;
+        if (k < ntri) {
+            // cull BACK (src/invert.cpp:1334).  For a ray from the origin o that meets the triangle's plane at
+            // p = o + t d, t > 0, det = e1 . (d x e2) = (p - o) . (e2 x e1) / t, and (p - o) . n is the same for every p
+            // of the plane: its sign at v0 decides for all rays at once.  With P0 = e2 x e1 as fold_triangle forms it
+            // and t0 = o - v0, det = d . P0 = -(t0 . P0) / t: back-facing for every ray when t0 . P0 is clearly
+            // positive (a margin of the products' rounding keeps the doubtful).
+            const float4 A = rA[u], B = rB[u], C = rC[u];
+            float4 P0, P1, P2;
+            fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
+            const float tx = f.ox - A.x, ty = f.oy - A.y, tz = f.oz - A.z;
+            const float sd = (tx * P0.x + ty * P0.y) + tz * P0.z;
+            const float mag = (fabsf(tx * P0.x) + fabsf(ty * P0.y)) + fabsf(tz * P0.z);
+            front = !(sd > 1e-4f * mag);
         }
-        eps = pair_eps(f.ox, f.oy, f.oz, dabs + dabs, A, B, C);
+        const uint32_t at = wave_append(&s_nfront, front, lane);
+        if (front) s_front[at] = k, s_recA[at] = rA[u], s_recB[at] = rB[u], s_recC[at] = rC[u];
     }
-    for (uint32_t py = y0; py <= y1; py++)
-        for (uint32_t px = x0; px <= x1; px++) {
-            float dx, dy, dz;
-            dir_at(f, (float)px + 0.5f, (float)py + 0.5f, dx, dy, dz);
-            const float det = __builtin_fmaf(dx, P0.x, __builtin_fmaf(dy, P0.y, dz * P0.z));
-            const float un = __builtin_fmaf(dx, P1.x, __builtin_fmaf(dy, P1.y, dz * P1.z));
-            const float vn = __builtin_fmaf(dx, P2.x, __builtin_fmaf(dy, P2.y, dz * P2.z));
-            const float e2 = eps + eps, hi = det + e2;
-            const float worst = fminf(fminf(fminf(det + eps, un + eps), fminf(hi - un, vn + eps)), (hi + eps) - (un + vn));
-            if (worst < 0.0f) continue; // (a NaN goes on to the exact test)
-            if (f.nranks > 1) { // another rank's tile
-                uint64_t dummy;
-                if (!out_index(f, px, py, dummy)) continue;
+    __syncthreads();
+    const uint32_t nfront = s_nfront;
+    for (uint32_t base = threadIdx.x & ~63u; base < nfront; base += 256u) { // wave-uniform: 64 listed triangles a trip
+        const bool have = base + lane < nfront;
+        const uint32_t at = have ? base + lane : 0u, k = s_front[at];
+        const float4 A = s_recA[at], B = s_recB[at], C = s_recC[at];
+        float4 P0, P1, P2;
+        fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
+        // The pixels whose centre ray can pass the full test lie inside the triangle's projection, give or take the
+        // roundings of the test and of the ray (a few 1e-4 pixel at most): the three vertices through the frame's
+        // matrix, their pixel bounds widened by an eighth of a pixel.  A vertex at or behind the eye's plane (the
+        // launcher only takes scenes that lie in front of it) makes the triangle claim the whole frame.
+        const float vx[3] = {A.x, A.x + B.x, A.x + C.x}, vy[3] = {A.y, A.y + B.y, A.y + C.y}, vz[3] = {A.z, A.z + B.z, A.z + C.z};
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        bool whole = false;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float xv = (f.mv[0] * vx[c] + f.mv[1] * vy[c]) + (f.mv[2] * vz[c] + f.mv[3]);
+            const float yv = (f.mv[4] * vx[c] + f.mv[5] * vy[c]) + (f.mv[6] * vz[c] + f.mv[7]);
+            const float zv = (f.mv[8] * vx[c] + f.mv[9] * vy[c]) + (f.mv[10] * vz[c] + f.mv[11]);
+            const float w = -zv; // w_clip of a GLM perspective
+            const float rw = 1.0f / w;
+            const float fx = ((f.p00 * xv) * rw + 1.0f) * (0.5f * f.wf);
+            const float fy = ((f.p11 * yv) * rw + 1.0f) * (0.5f * f.hf);
+            whole = whole || !(w > 1e-30f) || !(fx == fx) || !(fy == fy);
+            xmin = fminf(xmin, fx), xmax = fmaxf(xmax, fx), ymin = fminf(ymin, fy), ymax = fmaxf(ymax, fy);
+        }
+        // pixel centres px + 0.5 inside [xmin - m, xmax + m], clipped to the rectangle that can contain hits
+        const float m = 0.125f;
+        float fx0 = ceilf(xmin - m - 0.5f), fx1 = floorf(xmax + m - 0.5f);
+        float fy0 = ceilf(ymin - m - 0.5f), fy1 = floorf(ymax + m - 0.5f);
+        if (whole) fx0 = 0.0f, fy0 = 0.0f, fx1 = f.wf, fy1 = f.hf;
+        uint32_t x0 = 1, x1 = 0, y0 = 1, y1 = 0; // an empty rectangle
+        if (have && fx1 >= (float)f.rx0 && fy1 >= (float)f.ry0 && fx0 <= (float)f.rx1 - 1.0f && fy0 <= (float)f.ry1 - 1.0f) {
+            x0 = (uint32_t)fmaxf(fx0, (float)f.rx0), y0 = (uint32_t)fmaxf(fy0, (float)f.ry0);
+            x1 = (uint32_t)fminf(fx1, (float)f.rx1 - 1.0f), y1 = (uint32_t)fminf(fy1, (float)f.ry1 - 1.0f);
+        }
+        const bool some = x0 <= x1 && y0 <= y1;
+        // The cheap inside test of the tile kernel (mt_inside_pair, one record): the three dot products of the folded
+        // terms with the pixel's direction, every comparison widened by a bound on the roundings (of these products,
+        // of mt_test's own, and of the reciprocal multiplies in dir_at; f.dir_abs_max bounds the direction's
+        // components over the frame's hit rectangle).  Only pixels it lets through get their exact ray and the full
+        // test, which alone decides.
+        const float eps = pair_eps(f.ox, f.oy, f.oz, f.dir_abs_max + f.dir_abs_max, A, B, C);
+        // the pixel loop, every lane of the wave in step: trip i is the lane's i-th pixel, if it has that many
+        const uint32_t cols = some ? x1 - x0 + 1u : 0u, mine = some ? cols * (y1 - y0 + 1u) : 0u;
+        uint32_t trips = mine;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, o));
+        uint32_t px = x0, py = y0;
+        for (uint32_t i = 0; i < trips; i++) { // wave-uniform trip count
+            bool pass = false;
+            if (i < mine) {
+                float dx, dy, dz;
+                dir_at(f, (float)px + 0.5f, (float)py + 0.5f, dx, dy, dz);
+                const float det = __builtin_fmaf(dx, P0.x, __builtin_fmaf(dy, P0.y, dz * P0.z));
+                const float un = __builtin_fmaf(dx, P1.x, __builtin_fmaf(dy, P1.y, dz * P1.z));
+                const float vn = __builtin_fmaf(dx, P2.x, __builtin_fmaf(dy, P2.y, dz * P2.z));
+                const float e2 = eps + eps, hi = det + e2;
+                const float worst = fminf(fminf(fminf(det + eps, un + eps), fminf(hi - un, vn + eps)), (hi + eps) - (un + vn));
+                pass = !(worst < 0.0f); // (a NaN goes on to the exact test)
+                if (pass && f.nranks > 1) { // another rank's tile
+                    uint64_t dummy;
+                    pass = out_index(f, px, py, dummy);
+                }
             }
-            const Ray ray = make_ray(f, px, py, 0.5f, 0.5f);
-            Hit best = miss_hit();
-            mt_test(f, ray, A, B, C, k, best);
-            if (best.key != kMissKey) atomicMin(&vis[(size_t)py * f.w + px], (unsigned long long)best.key);
+            const uint32_t ap = wave_append(&s_npairs, pass, lane);
+            if (pass) {
+                if (ap < kPairCap)
+                    s_pairs[ap] = make_uint2(at, px | (py << 16));
+                else
+                    scatter_pair(f, k, px, py, A, B, C, vis); // the list is full: this pair right away
+            }
+            if (++px > x1) px = x0, py++;
         }
+    }
+    __syncthreads();
+    const uint32_t npairs = min(s_npairs, kPairCap);
+    for (uint32_t q = threadIdx.x; q < npairs; q += 256u) {
+        const uint2 e = s_pairs[q];
+        scatter_pair(f, s_front[e.x], e.y & 0xFFFFu, e.y >> 16, s_recA[e.x], s_recB[e.x], s_recC[e.x], vis);
+    }
 }
 
 // One lane per output pixel: the winner of the pixel's visibility entry is shaded and stored, and the entry is put
@@ -2229,7 +2290,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     if (vis && scatter_wanted(f, sc, out)) {
         // (nothing to try when the scene lies outside the frame: the resolve pass then stores clear values only)
         if (f.rx1 > f.rx0 && f.ry1 > f.ry0)
-            hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 255u) / 256u), dim3(256), 0, s, f, (const float4*)sc.triA,
+            hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 256u * kScatterPerLane - 1u) / (256u * kScatterPerLane)), dim3(256), 0, s, f, (const float4*)sc.triA,
                                (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, vis);
         const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
         if (f.rowmajor && f.nranks == 1 && !ao.rays && f.w % 4u == 0 && aligned16(out.color) && aligned16(out.depth) &&
