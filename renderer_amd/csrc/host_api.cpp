@@ -809,7 +809,7 @@ int inv_draw_path(const inv_scene* scene, const inv_camera* cam, const inv_param
     if (rc != INV_OK) return rc;
     const DeviceScene& d = scene->d;
     const Outputs none = {nullptr, nullptr, nullptr}; // (null pointers count as 16-byte aligned)
-    if ((params->flags & INV_BRUTE_FORCE) || !d.has_bvh || d.height > kStackDepth)
+    if ((params->flags & INV_BRUTE_FORCE) || !d.has_bvh)
         *path = INV_PATH_BRUTE;
     else if (params->flags & INV_LANE_TRAVERSAL)
         *path = INV_PATH_LANES;

@@ -142,7 +142,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
 #define INV_BATCH_MAX 8
 bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out);
 int tile_mode_for(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch);
-constexpr uint32_t kStackDepth = 40; // per-lane stack entries of the traversal kernels: deeper trees are drawn by brute force
+constexpr uint32_t kStackDepth = 40; // per-lane stack entries of the traversal kernels (a lane whose stack is full tests the far subtree leaf by leaf)
 hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
                                const DeviceScene& sc, const BinMem* bins);
 // Occlusion pass over the records the primary kernel queued (ao.rays > 0).

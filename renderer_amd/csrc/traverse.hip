@@ -61,7 +61,7 @@ constexpr bool kAoPend = INV_AO_PEND != 0;
 constexpr int kAoPull = INV_AO_PULL;        // idle lanes at which a wave hands out buffered occlusion rays
 constexpr int kAoLeafNum = INV_AO_LEAF_NUM; // eighths of the live lanes that must wait at a leaf before a leaf step
 constexpr unsigned long long kAoChunk = 64; // occlusion rays a wave sets up at a time (one per lane)
-constexpr int kStack = (int)kStackDepth; // per-lane stack entries; deeper trees use the brute-force kernel
+constexpr int kStack = (int)kStackDepth; // per-lane stack entries; a deeper tree makes a lane test a far subtree leaf by leaf
 constexpr int kFrontierCap = 256;  // nodes per breadth-first level kept in LDS
 constexpr int kRangeCap = 256;     // leaf ranges per tile
 // Candidate triangle records per tile (at most 64 per wave: one mask bit each).  The batched variant fills its list
@@ -184,20 +184,32 @@ __device__ __forceinline__ void trace(const FrameK& f, const Ray& r, const float
         float tn0, tn1;
         bool h0 = slab_folded(rs, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, tn0);
         bool h1 = slab_folded(rs, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, tn1);
-        if (h0 && (c0 & 0x80000000u)) {
-            const uint32_t k = c0 & 0x7FFFFFFFu;
-            mt_test(f, r, TA[k], TB[k], TC[k], k, best);
-            h0 = false;
+        const bool leaf0 = h0 && (c0 & 0x80000000u), leaf1 = h1 && (c1 & 0x80000000u);
+        h0 = h0 && !leaf0, h1 = h1 && !leaf1;
+        const bool first1 = tn1 < tn0;
+        // Both children are subtrees and the stack is full (only a tree deeper than it can do that): the far
+        // subtree's leaves are tested one by one (an internal node's record carries its first and last sorted leaf).
+        const bool spill = h0 && h1 && sp >= kStack;
+        uint32_t far_lo = 1u, far_hi = 0u;
+        if (spill) {
+            const float4 rg = nodes[4 * (size_t)(first1 ? c0 : c1) + 3];
+            far_lo = __float_as_uint(rg.z), far_hi = __float_as_uint(rg.w);
         }
-        if (h1 && (c1 & 0x80000000u)) {
-            const uint32_t k = c1 & 0x7FFFFFFFu;
-            mt_test(f, r, TA[k], TB[k], TC[k], k, best);
-            h1 = false;
+        // one copy of the triangle test for the three things a step can have to test: leaf child 0, leaf child 1,
+        // the leaves of a subtree that did not fit the stack
+#pragma nounroll
+        for (int part = 0; part < 3; part++) {
+            uint32_t ka = 1u, kb = 0u;
+            if (part == 0 && leaf0) ka = kb = c0 & 0x7FFFFFFFu;
+            if (part == 1 && leaf1) ka = kb = c1 & 0x7FFFFFFFu;
+            if (part == 2) ka = far_lo, kb = far_hi;
+            for (uint32_t k = ka; k <= kb; k++) mt_test(f, r, TA[k], TB[k], TC[k], k, best);
         }
         if (h0 && h1) {
-            const bool first1 = tn1 < tn0;
-            stack[(size_t)sp * stride] = first1 ? c0 : c1; // far child waits
-            sp++;
+            if (!spill) {
+                stack[(size_t)sp * stride] = first1 ? c0 : c1; // far child waits
+                sp++;
+            }
             node = first1 ? c1 : c0;
         } else if (h0) {
             node = c0;
@@ -477,19 +489,17 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
     // ---- phase 1 from the coarse cut (scenes without a fine cut, draws without a binning pass): groups of cut
     //      records, then the records of the surviving groups, one box per lane; whatever is still a subtree after
     //      that is opened breadth-first ----
-    // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
-    // ---- phase 1, flat (small scenes): the first two fine-cut records of this lane are fetched before anything else
+    // ---- phase 1, flat (small scenes): every fine-cut record against the frustum, two per lane and trip
     const bool flat_mode = !bin_count && nflat != 0u; // block-uniform
-    float4 fl_lo[2], fl_hi[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        fl_lo[u] = fl_hi[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const uint32_t q = (uint32_t)u * NT + tid;
-        if (flat_mode && q < nflat) fl_lo[u] = flat[2 * (size_t)q], fl_hi[u] = flat[2 * (size_t)q + 1];
-    }
     const uint32_t ngroups = bin_count || flat_mode ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
+    // the first box this lane tests (a group of the coarse cut, or a record of the fine cut) is fetched before
+    // anything else: the load is in flight across the first barrier
     float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
-    if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
+    if (flat_mode) {
+        if (tid < nflat) g_lo = flat[2 * (size_t)tid], g_hi = flat[2 * (size_t)tid + 1];
+    } else if (tid < ngroups) {
+        g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
+    }
     if (!bin_count) {
         if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.rec_overflow = 0, S.n_groups = 0;
         __syncthreads();
@@ -503,7 +513,8 @@ __device__ __forceinline__ void trace_tile(const FrameK& f, TileLds<NW, BATCHED 
                 bool in = false;
                 uint32_t first = 0, count = 0;
                 if (q < nflat) {
-                    const float4 lo = base ? flat[2 * (size_t)q] : fl_lo[u], hi = base ? flat[2 * (size_t)q + 1] : fl_hi[u];
+                    const bool pre = base == 0u && u == 0; // (compile-time u, block-uniform base)
+                    const float4 lo = pre ? g_lo : flat[2 * (size_t)q], hi = pre ? g_hi : flat[2 * (size_t)q + 1];
                     first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
                     in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
                 }
@@ -946,19 +957,17 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
     // ---- phase 1 from the coarse cut (scenes without a fine cut, draws without a binning pass): groups of cut
     //      records, then the records of the surviving groups, one box per lane; whatever is still a subtree after
     //      that is opened breadth-first ----
-    // the first boxes to test are fetched before anything else (the loads are in flight across the first barrier)
-    // ---- phase 1, flat (small scenes): the first two fine-cut records of this lane are fetched before anything else
+    // ---- phase 1, flat (small scenes): every fine-cut record against the frustum, two per lane and trip
     const bool flat_mode = !bin_count && nflat != 0u; // block-uniform
-    float4 fl_lo[2], fl_hi[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        fl_lo[u] = fl_hi[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const uint32_t q = (uint32_t)u * NT + tid;
-        if (flat_mode && q < nflat) fl_lo[u] = flat[2 * (size_t)q], fl_hi[u] = flat[2 * (size_t)q + 1];
-    }
     const uint32_t ngroups = bin_count || flat_mode ? 0u : (ncut + kCutGroup - 1u) / kCutGroup;
+    // the first box this lane tests (a group of the coarse cut, or a record of the fine cut) is fetched before
+    // anything else: the load is in flight across the first barrier
     float4 g_lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g_hi = g_lo;
-    if (tid < ngroups) g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
+    if (flat_mode) {
+        if (tid < nflat) g_lo = flat[2 * (size_t)tid], g_hi = flat[2 * (size_t)tid + 1];
+    } else if (tid < ngroups) {
+        g_lo = cut_groups[2 * (size_t)tid], g_hi = cut_groups[2 * (size_t)tid + 1];
+    }
     if (!bin_count) {
         if (tid == 0) S.n_front[0] = 0, S.n_front[1] = 0, S.n_ranges = 0, S.n_rec = 0, S.overflow = 0, S.n_groups = 0;
         __syncthreads();
@@ -972,7 +981,8 @@ __device__ __forceinline__ void trace_block(const FrameK& f, BlockLds& S, uint32
                 bool in = false;
                 uint32_t first = 0, count = 0;
                 if (q < nflat) {
-                    const float4 lo = base ? flat[2 * (size_t)q] : fl_lo[u], hi = base ? flat[2 * (size_t)q + 1] : fl_hi[u];
+                    const bool pre = base == 0u && u == 0; // (compile-time u, block-uniform base)
+                    const float4 lo = pre ? g_lo : flat[2 * (size_t)q], hi = pre ? g_hi : flat[2 * (size_t)q + 1];
                     first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
                     in = box_in_frustum(fr, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
                 }
@@ -1469,8 +1479,11 @@ __host__ __device__ inline uint32_t xcd_run_grid(uint32_t ntiles) { // tile work
 }
 
 // Grid = [blocks of the hit rectangle] ++ [fill blocks]; workgroups of four waves.
+#ifndef INV_TILES_PER_CU
+#define INV_TILES_PER_CU 5
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256, MODE == kBatched ? 1 : (MODE == kTiles ? 5 : 4)) void k_render_tile(FrameK f, TilePlan pl,
+__global__ __launch_bounds__(256, MODE == kBatched ? 1 : (MODE == kTiles ? INV_TILES_PER_CU : 4)) void k_render_tile(FrameK f, TilePlan pl,
                                                          const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                          const float4* __restrict__ TC, const float4* __restrict__ nodes,
                                                          const float4* __restrict__ cut,
@@ -1916,7 +1929,7 @@ __global__ __launch_bounds__(256) void k_vis_fill(unsigned long long* __restrict
 // ------------------------------------------------------------------------------------------------
 // occlusion pass over the pixels the primary kernel queued
 // ------------------------------------------------------------------------------------------------
-// Scenes without an LBVH (fewer than two triangles, or a tree deeper than the stack): one wave per queued pixel,
+// Scenes without an LBVH (fewer than two triangles): one wave per queued pixel,
 // one lane per ray, every triangle tested.
 __global__ __launch_bounds__(256) void k_ao_brute(FrameK f, AoK ao, const float4* __restrict__ TA,
                                                   const float4* __restrict__ TB, const float4* __restrict__ TC,
@@ -2216,7 +2229,7 @@ static size_t bin_counts_bytes(uint64_t nbins) { return Arena::aligned((size_t)n
 size_t bin_mem_bytes(uint64_t nbins) { return nbins ? bin_counts_bytes(nbins) + (size_t)nbins * kRangeCap * sizeof(uint2) : 0; }
 
 uint32_t tile_bins_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out, bool batch) {
-    if (f.npix == 0 || !sc.has_bvh || sc.nfine == 0 || sc.height > (uint32_t)kStack) return 0;
+    if (f.npix == 0 || !sc.has_bvh || sc.nfine == 0) return 0;
     if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE)) return 0;
     const int env = bins_env();
     (void)batch;
@@ -2255,7 +2268,7 @@ static int scatter_env() {
 }
 
 bool scatter_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out) {
-    if (f.npix == 0 || !sc.has_bvh || !sc.slot_of || sc.height > (uint32_t)kStack || f.spp != 1u) return false;
+    if (f.npix == 0 || !sc.has_bvh || !sc.slot_of || f.spp != 1u) return false;
     if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE | INV_BLOCKS)) return false;
     const int env = scatter_env();
     if (env == 0 || !eye_outside_scene(f, sc)) return false;
@@ -2274,7 +2287,7 @@ hipError_t launch_vis_fill(hipStream_t s, unsigned long long* vis, uint64_t n) {
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao,
                              const Outputs& out, const BinMem* bins, unsigned long long* vis) {
     if (f.npix == 0) return hipSuccess;
-    if (!sc.has_bvh || sc.height > (uint32_t)kStack) return launch_render_brute(s, f, sc, ao, out);
+    if (!sc.has_bvh) return launch_render_brute(s, f, sc, ao, out);
     if (f.flags & INV_LANE_TRAVERSAL) {
         uint32_t blocks;
         if (f.rowmajor) {
@@ -2334,7 +2347,7 @@ int tile_mode_for(const FrameK& f, const DeviceScene& sc, const Outputs& out, bo
 }
 
 bool tile_batchable(const FrameK& f, const DeviceScene& sc, const Outputs& out) {
-    if (f.npix == 0 || !sc.has_bvh || sc.height > (uint32_t)kStack) return false;
+    if (f.npix == 0 || !sc.has_bvh) return false;
     if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE)) return false;
     int mode = kBlocks;
     (void)plan_tile_frame(f, sc, out, true, &mode);
@@ -2376,14 +2389,16 @@ namespace inv {
 hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out) {
     if (!ao.rays || f.npix == 0) return hipSuccess;
     // fixed grids walk the queue (its length is only known on the device)
-    if (!sc.has_bvh || sc.height > (uint32_t)kStack) {
+    // The occlusion kernel's per-lane stacks hold as many entries as the tree is high, so they cannot overflow; a tree
+    // so deep that they do not fit the 64 KiB a workgroup may ask for (more than 53 levels over 32 768 triangles or
+    // more) goes the way of scenes without a tree.
+    const bool small = sc.ntri < 32768u; // child references fit 16 bits
+    const size_t lds = (size_t)(sc.height + 1u) * 256u * (small ? 2u : 4u) + 4u * kAoRayWords * 64u * sizeof(uint32_t);
+    if (!sc.has_bvh || lds > 64u * 1024u) {
         hipLaunchKernelGGL(k_ao_brute, dim3(1024), dim3(256), 0, s, f, ao, (const float4*)sc.triA,
                            (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, out);
         return hipGetLastError();
     }
-    const uint32_t entries = std::min<uint32_t>(sc.height + 1u, (uint32_t)kStack + 1u);
-    const bool small = sc.ntri < 32768u; // child references fit 16 bits
-    const size_t lds = (size_t)entries * 256u * (small ? 2u : 4u) + 4u * kAoRayWords * 64u * sizeof(uint32_t);
     // as many workgroups as stay resident at once: 256 CUs x what the stack's LDS share allows (at most 8)
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / (lds + 512u)));
     if (small)

@@ -788,3 +788,72 @@ def test_mesh_from_the_general_reader_renders(oracle, gpu_ctx, tmp_path):
     common.assert_frames_equal(got, want, "icosphere")
     assert (got[2] != 0xFFFFFFFF).sum() > 500
     scene.close()
+
+
+def _deep_tree_scene():
+    """Triangles whose Morton keys peel off one key bit per tree level: pairs of large triangles centred on points
+    that close in on one interior point P along alternating axes (the cell of P with one coordinate bit flipped, from
+    the top bit down), so the Karras tree over them is a chain some sixty levels deep, every level an internal node
+    (the pair) beside the rest of the chain.  The triangles are large and all overlap around P: a ray through there
+    meets both children at every level, and its stack of far children fills up."""
+    lo = np.array([-0.08, 0.03, -0.08])  # the bounds the keys are quantised on (pinned by two tiny triangles below):
+    ext = 0.16                            # every large triangle stays inside them
+    g = np.array([0x0CCD93, 0x0D1EE5, 0x0C7B7B])  # P's grid cell, 21 bits per axis: about 0.4 of the way along each
+    pts = []
+    for j in range(20, 0, -1):
+        for a in range(3):
+            q = g.copy()
+            q[a] ^= 1 << j
+            pts.append(q)
+    pts.append(g)
+    xyz, faces = [], []
+
+    def tri(c, s, flip):
+        n = len(xyz)
+        v = [(-s, -s, -s), (s, -s, s), (-s, s, s)] if not flip else [(s, s, s), (-s, s, -s), (s, -s, -s)]
+        for d in v:
+            xyz.append(c + np.array(d))
+        faces.append((n, n + 1, n + 2) if not flip else (n, n + 2, n + 1))
+
+    for k, q in enumerate(pts):
+        c = lo + (q + 0.5) / 2.0 ** 21 * ext
+        tri(c, 0.006 + 0.0003 * (k % 7), False)
+        tri(c, 0.006 + 0.0003 * (k % 5), True)
+    for corner in (lo, lo + ext):  # pin the bounds the keys are quantised on
+        tri(corner + np.where(corner == lo, 1e-6, -1e-6), 1e-6, False)
+    xyzw = np.ones((len(xyz), 4), np.float32)
+    xyzw[:, :3] = np.array(xyz)
+    return xyzw, np.array(faces, np.uint32).reshape(-1)
+
+
+def _tree_height(child):
+    depth = np.zeros(len(child), np.int64)
+    order = [0]
+    for i in order:  # parents before children
+        for c in child[i]:
+            if not (int(c) >> 31):
+                depth[int(c)] = depth[i] + 1
+                order.append(int(c))
+    return int(depth.max()) + 1
+
+
+def test_tree_deeper_than_the_traversal_stack(oracle, gpu_ctx):
+    """An LBVH of more levels than the per-lane stacks hold (40): the tile and block kernels draw it like any other
+    scene, and a lane whose stack fills up (their overflow path, INV_LANE_TRAVERSAL) tests the far subtree leaf by
+    leaf; the occlusion kernel sizes its stacks by the tree's height."""
+    xyzw, idx = _deep_tree_scene()
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    common.check_lbvh(oracle, scene, xyzw, idx)
+    assert _tree_height(scene.read_lbvh()["child"]) > 55
+    w, h = 640, 480
+    cam, ocam = R.camera_reference(w, h), oracle.camera_reference(w, h)
+    assert scene.draw_path(cam, R.make_params(w, h)) == R.api.PATH_TILES
+    for kw in (dict(flags=0), dict(flags=R.LANE_TRAVERSAL | R.LAMBERT), dict(flags=R.BLOCKS), dict(flags=R.LAMBERT, spp=4, seed=3),
+               dict(flags=R.LAMBERT | R.INVERT, ao_rays=16), dict(flags=R.LANE_TRAVERSAL, ao_rays=5, spp=1)):
+        prm = R.make_params(w, h, **kw)
+        got = scene.render(cam, prm)
+        want = oracle.render_bruteforce(xyzw, idx, ocam, _oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "deep tree %r" % (kw,))
+    assert (got[2] != 0xFFFFFFFF).sum() > 200
+    scene.close()
+
