@@ -1878,9 +1878,23 @@ __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, const float4
                                                           const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                           const uint32_t* __restrict__ slot_of, uint32_t ntri,
                                                           unsigned long long* __restrict__ vis, Outputs out) {
+#ifndef INV_RESOLVE_TILED
+#define INV_RESOLVE_TILED 1
+#endif
+#if INV_RESOLVE_TILED
+    // A wave takes a 16 x 16 pixel square, a lane four pixels of one of its rows: neighbouring pixels are won by
+    // triangles that lie close together in the sorted arrays, so the square's gathers (slot_of, the winners' records)
+    // share cache lines where a run of 256 pixels along one row would not.
+    const uint32_t squares_x = (f.w + 15u) >> 4, lane = threadIdx.x & 63u;
+    const uint32_t sq = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t px0 = (sq % squares_x) * 16u + (lane & 3u) * 4u, py = (sq / squares_x) * 16u + (lane >> 2);
+    if (px0 >= f.w || py >= f.h) return;
+    const uint32_t pix0 = py * f.w + px0;
+#else
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // group of four pixels
     if (q * 4u >= f.npix) return;
     const uint32_t pix0 = (uint32_t)(q * 4u), py = pix0 / f.w, px0 = pix0 - py * f.w;
+#endif
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     u64x2* const vp = (u64x2*)(vis + pix0);
     const u64x2 k01 = vp[0], k23 = vp[1];
@@ -1890,29 +1904,37 @@ __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, const float4
     if (k01.x != kMissKey || k01.y != kMissKey || k23.x != kMissKey || k23.y != kMissKey) { // some pixel was hit
         const u64x2 miss2 = {kMissKey, kMissKey};
         vp[0] = miss2, vp[1] = miss2;
-        // the four lookups, then the four records, each set in flight together: a lane's pixels are independent
-        uint32_t slot[4];
-        bool hit[4];
+#ifndef INV_RESOLVE_GROUP
+#define INV_RESOLVE_GROUP 2
+#endif
+        // the lookups of INV_RESOLVE_GROUP pixels, then their records, each set in flight together: a lane's pixels
+        // are independent (fewer at a time: fewer registers, more waves per SIMD)
+        constexpr int G = INV_RESOLVE_GROUP;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            hit[j] = keys[j] != kMissKey && (uint32_t)keys[j] < ntri; // (the second test never fails for keys the first pass wrote)
-            slot[j] = hit[j] ? slot_of[(uint32_t)keys[j]] : 0u;
-        }
-        float4 A[4], B[4], C[4];
+        for (int j0 = 0; j0 < 4; j0 += G) {
+            uint32_t slot[G];
+            bool hit[G];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (hit[j]) A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
-            Hit first = miss_hit();
-            if (hit[j]) {
-                const Ray ray0 = make_ray(f, px0 + (uint32_t)j, py, 0.5f, 0.5f);
-                mt_test(f, ray0, A[j], B[j], C[j], slot[j], first); // the same test again: the same key, now with its terms
-                if (first.key != kMissKey) shade_hit(f, first, A[j], B[j], C[j], r, g, b);
+            for (int j = 0; j < G; j++) {
+                hit[j] = keys[j0 + j] != kMissKey && (uint32_t)keys[j0 + j] < ntri; // (the second test never fails for keys the first pass wrote)
+                slot[j] = hit[j] ? slot_of[(uint32_t)keys[j0 + j]] : 0u;
             }
-            col[j] = pack_pixel(f.flags, r, g, b);
-            dep[j] = (uint32_t)(first.key >> 32), pid[j] = (uint32_t)first.key;
+            float4 A[G], B[G], C[G];
+#pragma unroll
+            for (int j = 0; j < G; j++)
+                if (hit[j]) A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]];
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
+                Hit first = miss_hit();
+                if (hit[j]) {
+                    const Ray ray0 = make_ray(f, px0 + (uint32_t)(j0 + j), py, 0.5f, 0.5f);
+                    mt_test(f, ray0, A[j], B[j], C[j], slot[j], first); // the same test again: the same key, now with its terms
+                    if (first.key != kMissKey) shade_hit(f, first, A[j], B[j], C[j], r, g, b);
+                }
+                col[j0 + j] = pack_pixel(f.flags, r, g, b);
+                dep[j0 + j] = (uint32_t)(first.key >> 32), pid[j0 + j] = (uint32_t)first.key;
+            }
         }
     }
 #define INV_ST16_NT(p, v) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory")
@@ -2307,11 +2329,16 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
                                (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, vis);
         const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
         if (f.rowmajor && f.nranks == 1 && !ao.rays && f.w % 4u == 0 && aligned16(out.color) && aligned16(out.depth) &&
-            aligned16(out.primid))
-            hipLaunchKernelGGL(k_scatter_resolve4, dim3((unsigned)((f.npix / 4 + 255) / 256)), dim3(256), 0, s, f,
+            aligned16(out.primid)) {
+#if INV_RESOLVE_TILED
+            const unsigned resolve_blocks = (((f.w + 15u) >> 4) * ((f.h + 15u) >> 4) + 3u) / 4u;
+#else
+            const unsigned resolve_blocks = (unsigned)((f.npix / 4 + 255) / 256);
+#endif
+            hipLaunchKernelGGL(k_scatter_resolve4, dim3(resolve_blocks), dim3(256), 0, s, f,
                                (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
                                (const uint32_t*)sc.slot_of, sc.ntri, vis, out);
-        else
+        } else
             hipLaunchKernelGGL(k_scatter_resolve, dim3((unsigned)((f.npix + 255) / 256)), dim3(256), 0, s, f,
                                (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
                                (const uint32_t*)sc.slot_of, sc.ntri, vis, ao, out);
