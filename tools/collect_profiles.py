@@ -25,6 +25,8 @@ def main():
         "tile_stats.txt": "tile_stats.txt", "block_stats.txt": "block_stats.txt",
         "phase_timing_blocks.txt": "block_phase_timing.txt", "pmc_phases.txt": "tile_instruction_mix.txt", "config4.txt": "config4.txt",
         "pmc_cache.txt": "l2_valu_counters.txt", "build_timeline.txt": "lbvh_build_timeline.txt", "pmc_ao.txt": "ao_instruction_mix.txt",
+        "bench_ao64_closeup.json": "bench_bunny_1080p_ao64_closeup.json", "bench_single_draw.json": "bench_bunny_1080p_single_draw.json",
+        "pmc_4k.txt": "4k_16spp_counters.txt", "pmc_x1024.txt": "x1024_counters.txt", "build_probe.txt": "build_probe.txt",
     }
     for s, d in names.items():
         p = os.path.join(src, s)

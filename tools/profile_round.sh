@@ -13,6 +13,8 @@ timeout -k 10 200 python3 bench.py > "$O/bench_default.json"
 timeout -k 10 200 python3 bench.py --workload bunny_4k_16spp > "$O/bench_4k_16spp.json"
 timeout -k 10 200 python3 bench.py --workload bunny_1080p_ao64 > "$O/bench_ao64.json"
 timeout -k 10 250 python3 bench.py --workload bunny_x1024_1080p --steps 5 --warmup 1 > "$O/bench_x1024.json"
+timeout -k 10 250 python3 bench.py --workload bunny_1080p_ao64_closeup --no-cpu-baseline --steps 4 --warmup 1 --frames-per-step 16 > "$O/bench_ao64_closeup.json"
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --frames-in-flight 1 --frames-per-launch 1 > "$O/bench_single_draw.json"
 (cd /tmp && timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $B > /dev/null 2>&1)
 (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- $B > /dev/null 2>&1)
 (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- $B > /dev/null 2>&1)
@@ -29,4 +31,7 @@ timeout -k 10 300 python3 tools/config4.py > "$O/config4.txt" 2>&1
 python3 tools/build_timeline.py "$O"/build_trace/*/*_kernel_trace.csv > "$O/build_timeline.txt" 2>&1
 bash tools/pmc_cache.sh > /dev/null 2>&1 && cp gpurun_out/pmc_cache.txt "$O/pmc_cache.txt"
 bash tools/pmc_ao.sh > /dev/null 2>&1 && cp gpurun_out/pmc_ao.txt "$O/pmc_ao.txt"
+bash tools/pmc_4k.sh > "$O/pmc_4k.txt" 2>&1
+bash tools/pmc_x1024.sh > "$O/pmc_x1024.txt" 2>&1
+timeout -k 10 200 python3 tools/build_probe.py > "$O/build_probe.txt" 2>&1
 echo done
