@@ -112,6 +112,36 @@ int main(int argc, char** argv) {
         uint32_t rect[4] = {x0, y0, x0 + rnd() % (p.width - x0 + 1), y0 + rnd() % (p.height - y0 + 1)}, grid[4];
         const int rc = inv_sparse_layout(&p, rect, grid, &npix, ids, 64, &nt);
         EXPECT(p.nranks > 1 ? rc == INV_OK : rc == INV_ERR_ARG);
+        // rank 0 without tiles: three ranks or more, the tiles dealt to the others
+        p.flags |= INV_ROOT_IDLE;
+        const int ri = inv_sparse_layout(&p, rect, grid, &npix, ids, 64, &nt);
+        EXPECT(p.nranks >= 3 ? ri == INV_OK && (p.rank != 0 || nt == 0) : ri == INV_ERR_ARG);
+        const int rd = inv_tile_layout(&p, &npix, ids, 64, &nt);
+        EXPECT(p.nranks >= 3 ? rd == INV_OK && (p.rank != 0 || (nt == 0 && npix == 0)) : rd == INV_ERR_ARG);
+    }
+    {
+        // argument caps: extents, samples, ranks (the layout arithmetic is 64-bit up to them and refused beyond)
+        const uint32_t huge[] = {65537u, 0x7FFFFFFFu, 0x80000000u, 0xFFFFFFFFu};
+        for (uint32_t v : huge) {
+            inv_params p = {};
+            uint64_t npix = 0;
+            uint32_t nt = 0;
+            p.width = v, p.height = 1;
+            EXPECT(inv_tile_layout(&p, &npix, nullptr, 0, &nt) == INV_ERR_ARG);
+            p.width = 1, p.height = v;
+            EXPECT(inv_tile_layout(&p, &npix, nullptr, 0, &nt) == INV_ERR_ARG);
+            p.width = 64, p.height = 64, p.spp = v;
+            EXPECT(inv_tile_layout(&p, &npix, nullptr, 0, &nt) == INV_ERR_ARG);
+            p.spp = 1, p.nranks = v, p.rank = 1;
+            EXPECT(inv_tile_layout(&p, &npix, nullptr, 0, &nt) == INV_ERR_ARG);
+        }
+        inv_params p = {};
+        uint64_t npix = 0;
+        uint32_t nt = 0;
+        p.width = 65536, p.height = 32767, p.spp = 4096, p.nranks = 65536, p.rank = 65535, p.tile = 1024;
+        EXPECT(inv_tile_layout(&p, &npix, nullptr, 0, &nt) == INV_OK && npix == 1024ull * 1024ull && nt <= 1);
+        p.width = 65536, p.height = 32768; // 2^31 pixels
+        EXPECT(inv_tile_layout(&p, &npix, nullptr, 0, &nt) == INV_ERR_ARG);
     }
     std::vector<uint8_t> color(4 * 33 * 17, 128);
     std::vector<float> depth(33 * 17, 0.5f);
