@@ -117,6 +117,7 @@ void dfree(T*& p) {
 
 void free_device_scene(DeviceScene& d) {
     dfree(d.arena); // every array of the scene lives in this one allocation
+    dfree(d.wnodes); // (but the occlusion kernel's wide nodes, made on demand)
     d.xyzw = nullptr, d.idx = nullptr, d.triA = d.triB = d.triC = nullptr;
     d.morton = nullptr, d.order = d.child = d.parent = d.leaf_parent = nullptr, d.nodes = d.cut = d.cut_groups = d.fine = nullptr, d.slot_of = nullptr;
 }
@@ -767,7 +768,21 @@ int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_
         if (scatter && (rc = ensure_vis(stream, fs, (uint64_t)f.w * f.h)) != INV_OK) return rc;
         HIP_TRY(launch_render_bvh(stream, f, scene->d, ao, dev, nbins ? &fs.bins : nullptr, scatter ? fs.vis : nullptr));
     }
-    HIP_TRY(launch_ao(stream, f, scene->d, ao, dev));
+    if (ao.rays && !noalloc && scene->d.has_bvh && !scene->d.wnodes) {
+        // the first draw of this scene with occlusion rays: the occlusion kernel's four-wide node records, derived
+        // from the LBVH once (64 bytes per internal node; the entry point that allocates nothing walks the two-wide
+        // records instead).  Other frame slots may draw with them next, so their making is waited for.
+        uint32_t* w = nullptr;
+        HIP_TRY(hipMalloc((void**)&w, (size_t)(scene->d.ntri - 1u) * 64u));
+        hipError_t e = launch_make_wnodes(stream, scene->d, w);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) {
+            (void)hipFree(w);
+            return fail(INV_ERR_HIP, std::string("wide nodes: ") + hipGetErrorString(e));
+        }
+        scene->d.wnodes = w;
+    }
+    HIP_TRY(launch_ao(stream, f, scene->d, ao, dev, noalloc));
     if (!out->on_device) {
         if (out->color) HIP_TRY(hipMemcpyAsync(out->color, dev.color, f.npix * 4, hipMemcpyDeviceToHost, stream));
         if (out->depth) HIP_TRY(hipMemcpyAsync(out->depth, dev.depth, f.npix * 4, hipMemcpyDeviceToHost, stream));

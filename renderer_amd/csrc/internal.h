@@ -100,6 +100,9 @@ struct DeviceScene {
     uint32_t* slot_of = nullptr;   // ntri: primitive id -> storage slot (the inverse of `order`)
     float* nodes = nullptr;        // 16 floats per internal node: two child boxes, two child refs, leaf range
     uint32_t* qnodes = nullptr;    // 8 words per internal node: the child boxes on the grid of qgrid_for(bbox), see QGrid
+    uint32_t* wnodes = nullptr;    // 16 words per internal node: its (up to four) grandchildren in the format of qnodes'
+                                   // halves, for the occlusion kernel; an allocation of its own, made by the first draw
+                                   // with occlusion rays (launch_make_wnodes)
     float* cut = nullptr;          // kCutCap records of 8 floats: lo xyz, first leaf | node, hi xyz, leaf count
     float* cut_groups = nullptr;   // boxes of kCutGroup consecutive cut records: 8 floats each
     uint32_t ncut = 0;             // records in use
@@ -145,8 +148,11 @@ int tile_mode_for(const FrameK& f, const DeviceScene& sc, const Outputs& out, bo
 constexpr uint32_t kStackDepth = 40; // per-lane stack entries of the traversal kernels (a lane whose stack is full tests the far subtree leaf by leaf)
 hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
                                const DeviceScene& sc, const BinMem* bins);
+// Fills `wnodes` (64 bytes per internal node of `sc`) from sc.qnodes.
+hipError_t launch_make_wnodes(hipStream_t s, const DeviceScene& sc, uint32_t* wnodes);
 // Occlusion pass over the records the primary kernel queued (ao.rays > 0).
-hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
+// `narrow`: walk the two-wide records even if the wide ones exist.
+hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out, bool narrow = false);
 hipError_t launch_deinterleave_sparse(hipStream_t s, const FrameK& f, const uint32_t* gathered, uint64_t rank_stride,
                                       uint64_t plane_stride, uint32_t nplanes, uint32_t* frame,
                                       uint64_t frame_plane_stride);

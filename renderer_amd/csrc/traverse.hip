@@ -2018,7 +2018,15 @@ constexpr uint32_t kNoNode = 0x7FFFFFFFu;
 // __ballot goes through a vector compare).
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-template <typename StackT>
+// One entry of a node record (a box on the scene's 16-bit grid and a child reference) against the ray's slab terms.
+__device__ __forceinline__ bool slab_entry(const RaySlabs& rs, const uint4& e, float tmax, float& tnear) {
+    return slab_folded(rs, (float)(e.x & 0xFFFFu), (float)(e.x >> 16), (float)(e.y & 0xFFFFu), (float)(e.y >> 16),
+                       (float)(e.z & 0xFFFFu), (float)(e.z >> 16), tmax, tnear);
+}
+
+// WIDE: the node records are the four-wide ones (an internal node's grandchildren, or a child that is a leaf, in up
+// to four entries; unused entries refer to kNoNode): half as many node steps per ray, each with four box tests.
+template <typename StackT, bool WIDE>
 __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __restrict__ TA,
                                             const float4* __restrict__ TB, const float4* __restrict__ TC,
                                             const uint4* __restrict__ qnodes, QGrid grid, Outputs out) {
@@ -2123,27 +2131,55 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
                 if (!kAoPend) node = sp ? unpacked(stack[(size_t)(--sp) * 256]) : kNoNode;
             }
         } else if (at_node) {
-            const uint4 a0 = qnodes[2 * (size_t)node], a1 = qnodes[2 * (size_t)node + 1];
-            const uint32_t c0 = a0.w, c1 = a1.w;
-            float tn0, tn1;
-            // (packed multiply-adds for the twelve plane terms were slower: 2.03 against 1.93 ms for the close-up)
-            const bool h0 = slab_folded(rs, (float)(a0.x & 0xFFFFu), (float)(a0.x >> 16), (float)(a0.y & 0xFFFFu),
-                                        (float)(a0.y >> 16), (float)(a0.z & 0xFFFFu), (float)(a0.z >> 16), tlim, tn0);
-            const bool h1 = slab_folded(rs, (float)(a1.x & 0xFFFFu), (float)(a1.x >> 16), (float)(a1.y & 0xFFFFu),
-                                        (float)(a1.y >> 16), (float)(a1.z & 0xFFFFu), (float)(a1.z >> 16), tlim, tn1);
-            if (h0 && h1) { // nearer child first: an occluder close to the surface ends the ray soonest
-                const bool first1 = tn1 < tn0;
-                stack[(size_t)sp * 256] = packed(first1 ? c0 : c1);
-                sp++;
-                node = first1 ? c1 : c0;
-            } else if (h0) {
-                node = c0;
-            } else if (h1) {
-                node = c1;
-            } else if (sp == 0) {
-                node = kNoNode;
+            if constexpr (WIDE) {
+                const uint4* const w = qnodes + 4 * (size_t)node;
+                const uint4 e0 = w[0], e1 = w[1], e2 = w[2], e3 = w[3];
+                float t0, t1, t2, t3;
+                const bool h0 = slab_entry(rs, e0, tlim, t0), h1 = slab_entry(rs, e1, tlim, t1) && e1.w != kNoNode;
+                const bool h2 = slab_entry(rs, e2, tlim, t2) && e2.w != kNoNode, h3 = slab_entry(rs, e3, tlim, t3) && e3.w != kNoNode;
+                // the nearest of the hit children goes on (an occluder close to the surface ends the ray soonest), the
+                // others wait on the stack
+                float tb = INFINITY;
+                uint32_t nb = kNoNode;
+                if (h0) tb = t0, nb = e0.w;
+                if (h1 && t1 < tb) tb = t1, nb = e1.w;
+                if (h2 && t2 < tb) tb = t2, nb = e2.w;
+                if (h3 && t3 < tb) tb = t3, nb = e3.w;
+                // every entry is written at the stack's top and the top moves only past those that wait: the next write
+                // lands on an entry that does not (the stack has one entry of slack for the last)
+                stack[(size_t)sp * 256] = packed(e0.w), sp += (uint32_t)(h0 && e0.w != nb);
+                stack[(size_t)sp * 256] = packed(e1.w), sp += (uint32_t)(h1 && e1.w != nb);
+                stack[(size_t)sp * 256] = packed(e2.w), sp += (uint32_t)(h2 && e2.w != nb);
+                stack[(size_t)sp * 256] = packed(e3.w), sp += (uint32_t)(h3 && e3.w != nb);
+                if (nb != kNoNode)
+                    node = nb;
+                else if (sp == 0)
+                    node = kNoNode;
+                else
+                    node = unpacked(stack[(size_t)(--sp) * 256]);
             } else {
-                node = unpacked(stack[(size_t)(--sp) * 256]);
+                const uint4 a0 = qnodes[2 * (size_t)node], a1 = qnodes[2 * (size_t)node + 1];
+                const uint32_t c0 = a0.w, c1 = a1.w;
+                float tn0, tn1;
+                // (packed multiply-adds for the twelve plane terms were slower: 2.03 against 1.93 ms for the close-up)
+                const bool h0 = slab_folded(rs, (float)(a0.x & 0xFFFFu), (float)(a0.x >> 16), (float)(a0.y & 0xFFFFu),
+                                            (float)(a0.y >> 16), (float)(a0.z & 0xFFFFu), (float)(a0.z >> 16), tlim, tn0);
+                const bool h1 = slab_folded(rs, (float)(a1.x & 0xFFFFu), (float)(a1.x >> 16), (float)(a1.y & 0xFFFFu),
+                                            (float)(a1.y >> 16), (float)(a1.z & 0xFFFFu), (float)(a1.z >> 16), tlim, tn1);
+                if (h0 && h1) { // nearer child first: an occluder close to the surface ends the ray soonest
+                    const bool first1 = tn1 < tn0;
+                    stack[(size_t)sp * 256] = packed(first1 ? c0 : c1);
+                    sp++;
+                    node = first1 ? c1 : c0;
+                } else if (h0) {
+                    node = c0;
+                } else if (h1) {
+                    node = c1;
+                } else if (sp == 0) {
+                    node = kNoNode;
+                } else {
+                    node = unpacked(stack[(size_t)(--sp) * 256]);
+                }
             }
         }
         if (active && !ended) {
@@ -2422,14 +2458,46 @@ hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Output
 } // namespace inv
 
 namespace inv {
-hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out) {
+namespace {
+// An internal node's four-wide record: each child that is a leaf as it stands in the node's two-wide record, each
+// child that is an internal node replaced by that node's own two entries.
+__global__ __launch_bounds__(256) void k_make_wnodes(const uint4* __restrict__ qnodes, uint32_t n_internal,
+                                                     uint4* __restrict__ wnodes) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_internal) return;
+    uint4* const dst = wnodes + 4 * (size_t)i;
+    uint32_t pos = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint4 c = qnodes[2 * (size_t)i + k];
+        if (c.w & 0x80000000u) {
+            dst[pos++] = c;
+        } else {
+            dst[pos++] = qnodes[2 * (size_t)c.w];
+            dst[pos++] = qnodes[2 * (size_t)c.w + 1];
+        }
+    }
+    while (pos < 4u) dst[pos++] = make_uint4(0u, 0u, 0u, kNoNode);
+}
+} // namespace
+
+hipError_t launch_make_wnodes(hipStream_t s, const DeviceScene& sc, uint32_t* wnodes) {
+    if (!sc.has_bvh || sc.ntri < 2u) return hipSuccess;
+    hipLaunchKernelGGL(k_make_wnodes, dim3((sc.ntri - 1u + 255u) / 256u), dim3(256), 0, s, (const uint4*)sc.qnodes, sc.ntri - 1u,
+                       (uint4*)wnodes);
+    return hipGetLastError();
+}
+
+hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out, bool narrow) {
     if (!ao.rays || f.npix == 0) return hipSuccess;
     // fixed grids walk the queue (its length is only known on the device)
-    // The occlusion kernel's per-lane stacks hold as many entries as the tree is high, so they cannot overflow; a tree
-    // so deep that they do not fit the 64 KiB a workgroup may ask for (more than 53 levels over 32 768 triangles or
-    // more) goes the way of scenes without a tree.
+    // The occlusion kernel's per-lane stacks hold as many entries as a ray can have waiting, so they cannot overflow:
+    // one per level with the two-wide records, up to three per two levels (and one of slack) with the four-wide ones.
+    // A tree so deep that they do not fit the 64 KiB a workgroup may ask for goes the way of scenes without a tree.
+    const bool wide = !narrow && sc.wnodes != nullptr;
     const bool small = sc.ntri < 32768u; // child references fit 16 bits
-    const size_t lds = (size_t)(sc.height + 1u) * 256u * (small ? 2u : 4u) + 4u * kAoRayWords * 64u * sizeof(uint32_t);
+    const uint32_t entries = wide ? 3u * ((sc.height + 2u) / 2u) + 2u : sc.height + 1u;
+    const size_t lds = (size_t)entries * 256u * (small ? 2u : 4u) + 4u * kAoRayWords * 64u * sizeof(uint32_t);
     if (!sc.has_bvh || lds > 64u * 1024u) {
         hipLaunchKernelGGL(k_ao_brute, dim3(1024), dim3(256), 0, s, f, ao, (const float4*)sc.triA,
                            (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, out);
@@ -2437,12 +2505,18 @@ hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, cons
     }
     // as many workgroups as stay resident at once: 256 CUs x what the stack's LDS share allows (at most 8)
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / (lds + 512u)));
-    if (small)
-        hipLaunchKernelGGL(k_ao<uint16_t>, dim3(256u * per_cu), dim3(256), lds, s, f, ao, (const float4*)sc.triA,
-                           (const float4*)sc.triB, (const float4*)sc.triC, (const uint4*)sc.qnodes, qgrid_for(sc.bbox), out);
+    const dim3 grid(256u * per_cu), block(256);
+    const float4 *A = (const float4*)sc.triA, *B = (const float4*)sc.triB, *C = (const float4*)sc.triC;
+    const uint4* rec = (const uint4*)(wide ? sc.wnodes : sc.qnodes);
+    const QGrid qg = qgrid_for(sc.bbox);
+    if (small && wide)
+        hipLaunchKernelGGL((k_ao<uint16_t, true>), grid, block, lds, s, f, ao, A, B, C, rec, qg, out);
+    else if (small)
+        hipLaunchKernelGGL((k_ao<uint16_t, false>), grid, block, lds, s, f, ao, A, B, C, rec, qg, out);
+    else if (wide)
+        hipLaunchKernelGGL((k_ao<uint32_t, true>), grid, block, lds, s, f, ao, A, B, C, rec, qg, out);
     else
-        hipLaunchKernelGGL(k_ao<uint32_t>, dim3(256u * per_cu), dim3(256), lds, s, f, ao, (const float4*)sc.triA,
-                           (const float4*)sc.triB, (const float4*)sc.triC, (const uint4*)sc.qnodes, qgrid_for(sc.bbox), out);
+        hipLaunchKernelGGL((k_ao<uint32_t, false>), grid, block, lds, s, f, ao, A, B, C, rec, qg, out);
     if (out.color) hipLaunchKernelGGL(k_ao_resolve, dim3(512), dim3(256), 0, s, f, ao, out);
     return hipGetLastError();
 }
