@@ -770,8 +770,8 @@ int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_
     }
     if (ao.rays && !noalloc && scene->d.has_bvh && !scene->d.wnodes) {
         // the first draw of this scene with occlusion rays: the occlusion kernel's four-wide node records, derived
-        // from the LBVH once (64 bytes per internal node; the entry point that allocates nothing walks the two-wide
-        // records instead).  Other frame slots may draw with them next, so their making is waited for.
+        // from the LBVH once (64 bytes per internal node; the entry point that allocates nothing walks the LBVH's own
+        // two-wide records instead).  Other frame slots may draw with them next, so their making is waited for.
         uint32_t* w = nullptr;
         HIP_TRY(hipMalloc((void**)&w, (size_t)(scene->d.ntri - 1u) * 64u));
         hipError_t e = launch_make_wnodes(stream, scene->d, w);

@@ -62,10 +62,9 @@ struct Arena {
     }
 };
 
-// The occlusion kernel's node records: the two child boxes on a 16-bit grid over the scene's bounds, rounded outwards
-// by more than a grid step (so the rounding of the quantisation and of the ray's folded plane terms stays inside the
-// margin), and the two child references: 32 bytes instead of 64, two 16-byte loads per visited node instead of four.
-// Index k of axis a stands for the coordinate org[a] + k * step[a].
+// The occlusion kernel's node records hold child boxes on a 16-bit grid over the scene's bounds, rounded outwards by
+// more than a grid step (so the rounding of the quantisation and of the ray's folded plane terms stays inside the
+// margin): 12 bytes per box instead of 24.  Index k of axis a stands for the coordinate org[a] + k * step[a].
 struct QGrid {
     float lo[3], org[3], step[3], inv[3];
 };
@@ -99,10 +98,9 @@ struct DeviceScene {
     uint32_t* leaf_parent = nullptr; // ntri
     uint32_t* slot_of = nullptr;   // ntri: primitive id -> storage slot (the inverse of `order`)
     float* nodes = nullptr;        // 16 floats per internal node: two child boxes, two child refs, leaf range
-    uint32_t* qnodes = nullptr;    // 8 words per internal node: the child boxes on the grid of qgrid_for(bbox), see QGrid
-    uint32_t* wnodes = nullptr;    // 16 words per internal node: its (up to four) grandchildren in the format of qnodes'
-                                   // halves, for the occlusion kernel; an allocation of its own, made by the first draw
-                                   // with occlusion rays (launch_make_wnodes)
+    uint32_t* wnodes = nullptr;    // 16 words per internal node: its (up to four) grandchildren, each a box on the grid
+                                   // of qgrid_for(bbox) (see QGrid) and a child reference, for the occlusion kernel; an
+                                   // allocation of its own, made by the first draw with occlusion rays (launch_make_wnodes)
     float* cut = nullptr;          // kCutCap records of 8 floats: lo xyz, first leaf | node, hi xyz, leaf count
     float* cut_groups = nullptr;   // boxes of kCutGroup consecutive cut records: 8 floats each
     uint32_t ncut = 0;             // records in use
@@ -148,7 +146,7 @@ int tile_mode_for(const FrameK& f, const DeviceScene& sc, const Outputs& out, bo
 constexpr uint32_t kStackDepth = 40; // per-lane stack entries of the traversal kernels (a lane whose stack is full tests the far subtree leaf by leaf)
 hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Outputs* outs, uint32_t n,
                                const DeviceScene& sc, const BinMem* bins);
-// Fills `wnodes` (64 bytes per internal node of `sc`) from sc.qnodes.
+// Fills `wnodes` (64 bytes per internal node of `sc`) from sc.nodes.
 hipError_t launch_make_wnodes(hipStream_t s, const DeviceScene& sc, uint32_t* wnodes);
 // Occlusion pass over the records the primary kernel queued (ao.rays > 0).
 // `narrow`: walk the two-wide records even if the wide ones exist.

@@ -308,13 +308,14 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_permute(const float4* __restrict__ T, const uint32_t* __restrict__ order,
                                                  uint32_t n, float4* __restrict__ A1, float4* __restrict__ B1,
-                                                 float4* __restrict__ C1) {
+                                                 float4* __restrict__ C1, uint32_t* __restrict__ slot_of) {
     // (neighbours in Morton order are neighbours in space and often in the input: one L2 for a stretch of them)
     uint32_t i = xcd_block((n + 255u) / 256u) * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t s = order[i];
     const float4* rec = T + 3 * (size_t)s;
     A1[i] = rec[0], B1[i] = rec[1], C1[i] = rec[2];
+    slot_of[s] = i; // the inverse of `order`: primitive id -> sorted position
 }
 
 // ------------------------------------------------------------------------------------------
@@ -409,11 +410,6 @@ __device__ __forceinline__ void block_append(bool flag, uint32_t value, uint32_t
 }
 
 // primitive id -> storage slot, for kernels that know a pixel's winner by its primitive id only
-__global__ __launch_bounds__(256) void k_invert_order(const uint32_t* __restrict__ order, uint32_t n,
-                                                      uint32_t* __restrict__ slot_of) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < n) slot_of[order[k]] = k;
-}
 
 // The fine cut: every subtree (or single leaf) of at most kFineMax leaves whose parent covers more.  These subtrees
 // hold every leaf exactly once; a record is 8 floats, (lo.xyz, first sorted leaf) (hi.xyz, leaf count), the box being
@@ -456,23 +452,6 @@ __device__ __forceinline__ void emit_fine(bool finished, uint32_t c0, uint2 leav
     __syncthreads(); // the next call overwrites s_wave
 }
 
-// One internal node's record for the occlusion kernel (see QGrid): lower bounds rounded down and one step further,
-// upper bounds rounded up and one step further.
-__device__ __forceinline__ void write_qnode(uint32_t* __restrict__ qnodes, size_t i, const QGrid& g, const float b0[6],
-                                            const float b1[6], uint32_t c0, uint32_t c1) {
-    uint32_t q[12];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        q[a] = (uint32_t)fminf(fmaxf(floorf((b0[a] - g.lo[a]) * g.inv[a]), 0.0f), 65532.0f);
-        q[3 + a] = (uint32_t)fminf(fmaxf(ceilf((b0[3 + a] - g.lo[a]) * g.inv[a]), 0.0f), 65533.0f) + 2u;
-        q[6 + a] = (uint32_t)fminf(fmaxf(floorf((b1[a] - g.lo[a]) * g.inv[a]), 0.0f), 65532.0f);
-        q[9 + a] = (uint32_t)fminf(fmaxf(ceilf((b1[3 + a] - g.lo[a]) * g.inv[a]), 0.0f), 65533.0f) + 2u;
-    }
-    uint4* r = (uint4*)qnodes + 2 * i;
-    r[0] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), c0);
-    r[1] = make_uint4(q[6] | (q[7] << 16), q[8] | (q[9] << 16), q[10] | (q[11] << 16), c1);
-}
-
 // First the part of the tree that needs no exchange between workgroups.  Internal node i covers a range of sorted
 // leaves that contains leaf i, so every node whose range lies inside one chunk of kChunk consecutive leaves has its
 // index, its leaves and all of its descendants inside that chunk: one workgroup per chunk finishes those nodes in
@@ -493,8 +472,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
                                                          uint32_t* __restrict__ next, uint32_t* __restrict__ next_count,
                                                          uint32_t* __restrict__ finished_count,
                                                          float* __restrict__ fine, uint32_t* __restrict__ fine_count,
-                                                         uint32_t fine_cap, const float* __restrict__ bbox,
-                                                         uint32_t* __restrict__ qnodes) {
+                                                         uint32_t fine_cap) {
     __shared__ float s_leaf[6][kChunk]; // boxes of the chunk's leaves
     __shared__ float s_box[6][kChunk];  // boxes of the internal nodes finished here
     __shared__ uint32_t s_sweep[kChunk]; // sweep that finished the node, kOpen while it waits
@@ -546,7 +524,6 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
         nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
         nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
         nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
-        write_qnode(qnodes, i, qgrid_for(bbox), b0, b1, c0, c1);
         // the node's own box is read again only by a parent that is not finished here (or, the root's, by the host)
         const uint32_t p = parent[i] - base; // the root has no parent: 0xFFFFFFFF is in no chunk
         if (p >= kChunk || s_sweep[p] == kOpen) {
@@ -599,8 +576,7 @@ __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, co
                                                const uint32_t* __restrict__ parent,
                                                const uint2* __restrict__ range, uint32_t node,
                                                float* __restrict__ union_box, float* __restrict__ nodes, uint32_t& c0,
-                                               uint2& leaves, float b0[6], float b1[6], const float* __restrict__ bbox,
-                                               uint32_t* __restrict__ qnodes) {
+                                               uint2& leaves, float b0[6], float b1[6]) {
     c0 = child[2 * (size_t)node];
     const uint32_t c1 = child[2 * (size_t)node + 1];
     leaves = range[node];
@@ -619,7 +595,6 @@ __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, co
     u[1] = make_float4(fmaxf(h0[1], h1[1]), fmaxf(h0[2], h1[2]), __uint_as_float(ht), 0.0f);
 #pragma unroll
     for (int a = 0; a < 3; a++) b0[a] = l0[a], b0[3 + a] = h0[a], b1[a] = l1[a], b1[3 + a] = h1[a];
-    write_qnode(qnodes, node, qgrid_for(bbox), b0, b1, c0, c1);
     return parent[node];
 }
 
@@ -632,8 +607,7 @@ __global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ 
                                                      uint32_t* __restrict__ arrive, float* __restrict__ union_box,
                                                      float* __restrict__ nodes, uint32_t* __restrict__ next,
                                                      uint32_t* __restrict__ next_count, float* __restrict__ fine,
-                                                     uint32_t* __restrict__ fine_count, uint32_t fine_cap,
-                                                     const float* __restrict__ bbox, uint32_t* __restrict__ qnodes) {
+                                                     uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
     // The level's size is read on the device, so the host can queue several levels without waiting for each.
     const uint32_t nready = *ready_count;
     for (uint32_t base = blockIdx.x * blockDim.x; base < nready; base += gridDim.x * blockDim.x) { // block-uniform
@@ -641,7 +615,7 @@ __global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ 
         uint32_t up = 0xFFFFFFFFu, c0 = 0;
         uint2 leaves = make_uint2(0u, 0u);
         float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0};
-        if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes, c0, leaves, b0, b1, bbox, qnodes);
+        if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes, c0, leaves, b0, b1);
         emit_fine<256>(q < nready, c0, leaves, b0, b1, fine, fine_count, fine_cap);
         // the second child to arrive makes the parent ready for the next launch
         const bool second = up != 0xFFFFFFFFu && atomicAdd(&arrive[up], 1u) == 1u;
@@ -663,8 +637,7 @@ __global__ __launch_bounds__(kTailThreads) void k_refit_tail(const float4* __res
                                                              uint32_t max_level, uint32_t* __restrict__ arrive,
                                                              float* union_box, float* __restrict__ nodes,
                                                              float* __restrict__ fine, uint32_t* __restrict__ fine_count,
-                                                             uint32_t fine_cap, const float* __restrict__ bbox,
-                                                             uint32_t* __restrict__ qnodes) {
+                                                             uint32_t fine_cap) {
     __shared__ uint32_t s_nready;
     for (uint32_t level = first_level; level < max_level; level++) { // block-uniform
         if (threadIdx.x == 0) s_nready = __hip_atomic_load(ready_count + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -678,7 +651,7 @@ __global__ __launch_bounds__(kTailThreads) void k_refit_tail(const float4* __res
             uint32_t up = 0xFFFFFFFFu, c0 = 0;
             uint2 leaves = make_uint2(0u, 0u);
             float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0};
-            if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes, c0, leaves, b0, b1, bbox, qnodes);
+            if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes, c0, leaves, b0, b1);
             emit_fine<kTailThreads>(q < nready, c0, leaves, b0, b1, fine, fine_count, fine_cap);
             const bool second = up != 0xFFFFFFFFu && atomicAdd(&arrive[up], 1u) == 1u;
             block_append<kTailThreads>(second, up, next, ready_count + level + 1);
@@ -834,7 +807,7 @@ size_t lbvh_keep_bytes(uint32_t n) {
     if (n < 2) return 0;
     const size_t sizes[] = {(size_t)n * 8, (size_t)n * 4, (size_t)(n - 1) * 8, (size_t)(n - 1) * 4, (size_t)n * 4,
                             (size_t)(n - 1) * 64, (size_t)kCutCap * 32, (size_t)(kCutCap / kCutGroup) * 32,
-                            (size_t)fine_cap_for(n) * 32, (size_t)n * 4, (size_t)(n - 1) * 32};
+                            (size_t)fine_cap_for(n) * 32, (size_t)n * 4};
     size_t total = 0;
     for (size_t b : sizes) total += Arena::aligned(b);
     return total;
@@ -882,8 +855,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     sc.fine = keep.take<float>((size_t)fine_cap * 32);
     sc.nfine = 0;
     sc.slot_of = keep.take<uint32_t>((size_t)n * 4);
-    sc.qnodes = keep.take<uint32_t>((size_t)(n - 1) * 32);
-    if (!range || !sc.cut_groups || !sc.fine || !sc.slot_of || !sc.qnodes) return hipErrorOutOfMemory; // the arenas were sized for something else
+    if (!range || !sc.cut_groups || !sc.fine || !sc.slot_of) return hipErrorOutOfMemory; // the arenas were sized for something else
     float4 *A1 = (float4*)sc.triA, *B1 = (float4*)sc.triB, *C1 = (float4*)sc.triC;
 
     const float4* T0 = (const float4*)records;
@@ -912,8 +884,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
-    hipLaunchKernelGGL(k_permute, dim3(xcd_grid((n + 255) / 256)), blk, 0, s, T0, sc.order, n, A1, B1, C1);
-    hipLaunchKernelGGL(k_invert_order, grid_n, blk, 0, s, (const uint32_t*)sc.order, n, sc.slot_of);
+    hipLaunchKernelGGL(k_permute, dim3(xcd_grid((n + 255) / 256)), blk, 0, s, T0, sc.order, n, A1, B1, C1, sc.slot_of);
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
@@ -922,7 +893,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     const uint32_t nchunks = (n + kChunk - 1) / kChunk;
     hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, (const float4*)A1, (const float4*)B1,
                        (const float4*)C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, ready[0], ready_count,
-                       finished_in_chunks, sc.fine, fine_count, fine_cap, (const float*)d_bbox, sc.qnodes);
+                       finished_in_chunks, sc.fine, fine_count, fine_cap);
     HIP_RET(hipGetLastError());
     // The nodes that cross chunk boundaries: one launch per tree level; level L reads its size from ready_count[L] on
     // the device and appends the nodes that become ready to level L + 1.  The host does not know the tree's height:
@@ -943,7 +914,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     if (nchunks > 1 && nchunks <= kTailChunks) {
         hipLaunchKernelGGL(k_refit_tail, dim3(1), dim3(kTailThreads), 0, s, (const float4*)A1, (const float4*)B1,
                            (const float4*)C1, sc.child, sc.parent, range, ready[0], ready[1], ready_count, 0u, kMaxLevels,
-                           arrive, union_box, sc.nodes, sc.fine, fine_count, fine_cap, (const float*)d_bbox, sc.qnodes);
+                           arrive, union_box, sc.nodes, sc.fine, fine_count, fine_cap);
         level = want = kMaxLevels; // the cut kernel looks at the counter behind the last level
     }
     for (;;) {
@@ -951,8 +922,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
             const int cur = (int)(level & 1u);
             hipLaunchKernelGGL(k_refit_level, grid_level, blk, 0, s, (const float4*)A1, (const float4*)B1,
                                (const float4*)C1, sc.child, sc.parent, range, ready[cur], ready_count + level, arrive, union_box,
-                               sc.nodes, ready[cur ^ 1], ready_count + level + 1, sc.fine, fine_count, fine_cap,
-                               (const float*)d_bbox, sc.qnodes);
+                               sc.nodes, ready[cur ^ 1], ready_count + level + 1, sc.fine, fine_count, fine_cap);
         }
         hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
                            (const uint32_t*)(ready_count + level), (const float*)d_bbox, (const float*)union_box,

@@ -2025,11 +2025,13 @@ __device__ __forceinline__ bool slab_entry(const RaySlabs& rs, const uint4& e, f
 }
 
 // WIDE: the node records are the four-wide ones (an internal node's grandchildren, or a child that is a leaf, in up
-// to four entries; unused entries refer to kNoNode): half as many node steps per ray, each with four box tests.
+// to four entries on the scene's 16-bit grid; unused entries refer to kNoNode): half as many node steps per ray, each
+// with four box tests.  Otherwise they are the LBVH's own two-wide float records (a caller that may not allocate
+// the wide ones).
 template <typename StackT, bool WIDE>
 __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __restrict__ TA,
                                             const float4* __restrict__ TB, const float4* __restrict__ TC,
-                                            const uint4* __restrict__ qnodes, QGrid grid, Outputs out) {
+                                            const void* __restrict__ node_records, QGrid grid, Outputs out) {
     extern __shared__ uint32_t s_dyn[]; // [4 waves][kAoRayWords][64] ray buffers, then the stacks: one column per lane
     const uint32_t lane = threadIdx.x & 63u;
     float* const rb = (float*)s_dyn + (threadIdx.x >> 6) * (kAoRayWords * 64u);
@@ -2132,7 +2134,7 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
             }
         } else if (at_node) {
             if constexpr (WIDE) {
-                const uint4* const w = qnodes + 4 * (size_t)node;
+                const uint4* const w = (const uint4*)node_records + 4 * (size_t)node;
                 const uint4 e0 = w[0], e1 = w[1], e2 = w[2], e3 = w[3];
                 float t0, t1, t2, t3;
                 const bool h0 = slab_entry(rs, e0, tlim, t0), h1 = slab_entry(rs, e1, tlim, t1) && e1.w != kNoNode;
@@ -2158,14 +2160,13 @@ __global__ __launch_bounds__(256) void k_ao(FrameK f, AoK ao, const float4* __re
                 else
                     node = unpacked(stack[(size_t)(--sp) * 256]);
             } else {
-                const uint4 a0 = qnodes[2 * (size_t)node], a1 = qnodes[2 * (size_t)node + 1];
-                const uint32_t c0 = a0.w, c1 = a1.w;
+                // the LBVH's own node records (float boxes; the launcher passes the grid that leaves coordinates as they are)
+                const float4* const nd = (const float4*)node_records + 4 * (size_t)node;
+                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
                 float tn0, tn1;
-                // (packed multiply-adds for the twelve plane terms were slower: 2.03 against 1.93 ms for the close-up)
-                const bool h0 = slab_folded(rs, (float)(a0.x & 0xFFFFu), (float)(a0.x >> 16), (float)(a0.y & 0xFFFFu),
-                                            (float)(a0.y >> 16), (float)(a0.z & 0xFFFFu), (float)(a0.z >> 16), tlim, tn0);
-                const bool h1 = slab_folded(rs, (float)(a1.x & 0xFFFFu), (float)(a1.x >> 16), (float)(a1.y & 0xFFFFu),
-                                            (float)(a1.y >> 16), (float)(a1.z & 0xFFFFu), (float)(a1.z >> 16), tlim, tn1);
+                const bool h0 = slab_folded(rs, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlim, tn0);
+                const bool h1 = slab_folded(rs, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlim, tn1);
                 if (h0 && h1) { // nearer child first: an occluder close to the surface ends the ray soonest
                     const bool first1 = tn1 < tn0;
                     stack[(size_t)sp * 256] = packed(first1 ? c0 : c1);
@@ -2459,22 +2460,46 @@ hipError_t launch_render_batch(hipStream_t s, const FrameK* frames, const Output
 
 namespace inv {
 namespace {
-// An internal node's four-wide record: each child that is a leaf as it stands in the node's two-wide record, each
-// child that is an internal node replaced by that node's own two entries.
-__global__ __launch_bounds__(256) void k_make_wnodes(const uint4* __restrict__ qnodes, uint32_t n_internal,
+// A child box on the 16-bit grid of QGrid: lower bounds rounded down and one step further, upper bounds rounded up
+// and one step further, so that the quantised box holds the float box with room for the roundings of the index
+// arithmetic and of the ray's folded plane terms.
+__device__ __forceinline__ uint4 quantised_entry(const QGrid& g, const float lo[3], const float hi[3], uint32_t ref) {
+    uint32_t ql[3], qh[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        ql[a] = (uint32_t)fminf(fmaxf(floorf((lo[a] - g.lo[a]) * g.inv[a]), 0.0f), 65532.0f);
+        qh[a] = (uint32_t)fminf(fmaxf(ceilf((hi[a] - g.lo[a]) * g.inv[a]), 0.0f), 65533.0f) + 2u;
+    }
+    return make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), ref);
+}
+
+// The two entries (child box, child reference) of an LBVH node record.
+__device__ __forceinline__ void node_entries(const float4* __restrict__ nodes, uint32_t i, const QGrid& g, uint4& e0, uint4& e1) {
+    const float4 a = nodes[4 * (size_t)i], b = nodes[4 * (size_t)i + 1], c = nodes[4 * (size_t)i + 2], d = nodes[4 * (size_t)i + 3];
+    const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y}, lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
+    e0 = quantised_entry(g, lo0, hi0, __float_as_uint(d.x));
+    e1 = quantised_entry(g, lo1, hi1, __float_as_uint(d.y));
+}
+
+// An internal node's four-wide record: each child that is a leaf as it stands in the node's own record, each child
+// that is an internal node replaced by that node's two children.
+__global__ __launch_bounds__(256) void k_make_wnodes(const float4* __restrict__ nodes, uint32_t n_internal, QGrid g,
                                                      uint4* __restrict__ wnodes) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_internal) return;
     uint4* const dst = wnodes + 4 * (size_t)i;
+    uint4 c[2];
+    node_entries(nodes, i, g, c[0], c[1]);
     uint32_t pos = 0;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const uint4 c = qnodes[2 * (size_t)i + k];
-        if (c.w & 0x80000000u) {
-            dst[pos++] = c;
+        if (c[k].w & 0x80000000u) {
+            dst[pos++] = c[k];
         } else {
-            dst[pos++] = qnodes[2 * (size_t)c.w];
-            dst[pos++] = qnodes[2 * (size_t)c.w + 1];
+            uint4 e0, e1;
+            node_entries(nodes, c[k].w, g, e0, e1);
+            dst[pos++] = e0;
+            dst[pos++] = e1;
         }
     }
     while (pos < 4u) dst[pos++] = make_uint4(0u, 0u, 0u, kNoNode);
@@ -2483,8 +2508,8 @@ __global__ __launch_bounds__(256) void k_make_wnodes(const uint4* __restrict__ q
 
 hipError_t launch_make_wnodes(hipStream_t s, const DeviceScene& sc, uint32_t* wnodes) {
     if (!sc.has_bvh || sc.ntri < 2u) return hipSuccess;
-    hipLaunchKernelGGL(k_make_wnodes, dim3((sc.ntri - 1u + 255u) / 256u), dim3(256), 0, s, (const uint4*)sc.qnodes, sc.ntri - 1u,
-                       (uint4*)wnodes);
+    hipLaunchKernelGGL(k_make_wnodes, dim3((sc.ntri - 1u + 255u) / 256u), dim3(256), 0, s, (const float4*)sc.nodes, sc.ntri - 1u,
+                       qgrid_for(sc.bbox), (uint4*)wnodes);
     return hipGetLastError();
 }
 
@@ -2507,8 +2532,10 @@ hipError_t launch_ao(hipStream_t s, const FrameK& f, const DeviceScene& sc, cons
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / (lds + 512u)));
     const dim3 grid(256u * per_cu), block(256);
     const float4 *A = (const float4*)sc.triA, *B = (const float4*)sc.triB, *C = (const float4*)sc.triC;
-    const uint4* rec = (const uint4*)(wide ? sc.wnodes : sc.qnodes);
-    const QGrid qg = qgrid_for(sc.bbox);
+    const void* rec = wide ? (const void*)sc.wnodes : (const void*)sc.nodes;
+    QGrid qg = qgrid_for(sc.bbox);
+    if (!wide) // the LBVH's float records: index = coordinate
+        for (int a = 0; a < 3; a++) qg.lo[a] = 0.0f, qg.org[a] = 0.0f, qg.step[a] = 1.0f, qg.inv[a] = 1.0f;
     if (small && wide)
         hipLaunchKernelGGL((k_ao<uint16_t, true>), grid, block, lds, s, f, ao, A, B, C, rec, qg, out);
     else if (small)
