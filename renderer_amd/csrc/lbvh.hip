@@ -306,6 +306,39 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
 // ------------------------------------------------------------------------------------------
 // 4. gather the triangle records into sorted order
 // ------------------------------------------------------------------------------------------
+// The short form of the sort: five passes order the keys by their upper 40 bits (stably, so keys that agree there stay
+// in index order); what is left is to order every run of keys with equal upper bits by the lower 24.  Such runs are
+// triangles whose box centres share a cell of 1/8192 of the scene's extent per axis: one or a few, unless triangles
+// repeat.  Every key finds its run by looking at its neighbours and its place in it by counting the keys of the run
+// that go before it (smaller, or equal and earlier).  A run of more than kRunMax keys is copied as it is and the flag
+// is raised: the host then sorts again with all eight passes.  (A key looks at most kRunMax places either way, so
+// all keys of a run come to the same verdict: a shorter run is seen whole by each of them, a longer one is seen
+// whole and counted, or not seen whole.)
+constexpr int kShortSortShift = 24;
+constexpr uint32_t kRunMax = 48;
+__global__ __launch_bounds__(256) void k_sort_runs(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t n,
+                                                   uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                   uint32_t* __restrict__ too_long) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = kin[i], hi = k >> kShortSortShift;
+    uint32_t a = i, b = i + 1u;
+    while (a > 0u && i - a < kRunMax && (kin[a - 1u] >> kShortSortShift) == hi) a--;
+    while (b < n && b - i <= kRunMax && (kin[b] >> kShortSortShift) == hi) b++; // (b - i counts key i itself)
+    uint32_t at = i;
+    if (b - a > kRunMax) {
+        *too_long = 1u; // (every thread that comes here writes the same value)
+    } else if (b - a > 1u) {
+        uint32_t before = 0;
+        for (uint32_t j = a; j < b; j++) {
+            const uint64_t kj = kin[j];
+            before += (kj < k || (kj == k && j < i)) ? 1u : 0u;
+        }
+        at = a + before;
+    }
+    kout[at] = k, vout[at] = vin[i];
+}
+
 __global__ __launch_bounds__(256) void k_permute(const float4* __restrict__ T, const uint32_t* __restrict__ order,
                                                  uint32_t n, float4* __restrict__ A1, float4* __restrict__ B1,
                                                  float4* __restrict__ C1, uint32_t* __restrict__ slot_of) {
@@ -824,7 +857,19 @@ size_t lbvh_scratch_bytes(uint32_t n) {
     return total;
 }
 
+static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, bool short_sort);
+
 hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records) {
+    const size_t keep_used = keep.used, tmp_used = tmp.used;
+    hipError_t e = build_lbvh_with(s, sc, keep, tmp, records, true);
+    if (e == hipErrorNotReady) { // long runs of keys that agree in their upper bits (repeated triangles): all eight passes
+        keep.used = keep_used, tmp.used = tmp_used;
+        e = build_lbvh_with(s, sc, keep, tmp, records, false);
+    }
+    return e;
+}
+
+static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, bool short_sort) {
     const uint32_t n = sc.ntri;
     sc.has_bvh = false;
     if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
@@ -860,15 +905,19 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
 
     const float4* T0 = (const float4*)records;
     const dim3 blk(256), grid_n((n + 255) / 256);
+    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
+    uint32_t* const too_long = ready_count + kMaxLevels + 2 + 9; // summary word 9
     hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_blocks), blk, 0, s, T0, n, partial);
     hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, bounds_blocks, d_bbox);
     hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, n, d_bbox, sc.morton, sc.order);
-    // 63 significant key bits -> 8 passes; an even number of passes leaves the result in sc.morton / sc.order
+    // 63 significant key bits -> 8 passes; an even number of passes leaves the result in sc.morton / sc.order.  The
+    // short form: the upper five digits only (an odd number: the result is in the other pair of arrays), then
+    // k_sort_runs, which writes sc.morton / sc.order.
     uint64_t* kin = sc.morton;
     uint32_t* vin = sc.order;
     uint64_t* kout = keys_alt;
     uint32_t* vout = vals_alt;
-    for (int pass = 0; pass < 8; pass++) {
+    for (int pass = short_sort ? kShortSortShift / 8 : 0; pass < 8; pass++) {
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_sort_hist, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
         const uint32_t ncount = ntiles * 256u;
@@ -884,10 +933,10 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
+    if (short_sort) hipLaunchKernelGGL(k_sort_runs, grid_n, blk, 0, s, (const uint64_t*)kin, (const uint32_t*)vin, n, kout, vout, too_long);
     hipLaunchKernelGGL(k_permute, dim3(xcd_grid((n + 255) / 256)), blk, 0, s, T0, sc.order, n, A1, B1, C1, sc.slot_of);
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
-    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
     uint32_t* finished_in_chunks = ready_count + kMaxLevels + 1;
     uint32_t* fine_count = ready_count + kMaxLevels + 2 + 8;
     const uint32_t nchunks = (n + kChunk - 1) / kChunk;
@@ -930,6 +979,7 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
         HIP_RET(hipGetLastError());
         HIP_RET(hipMemcpyAsync(host_words, ready_count, sizeof host_words, hipMemcpyDeviceToHost, s));
         HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
+        if (short_sort && summary[9] != 0u) return hipErrorNotReady; // the caller sorts again with all eight passes
         if (level_count[level] == 0) break; // nothing is waiting for another level
         if (level >= kMaxLevels) return hipErrorUnknown; // a tree over 63+32-bit keys is at most 96 levels deep
         want = std::min<uint32_t>(kMaxLevels, level + 16u);

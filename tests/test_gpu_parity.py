@@ -612,6 +612,27 @@ def test_lbvh_structure_random(oracle, gpu_ctx, ntri, seed):
     scene.close()
 
 
+@pytest.mark.parametrize("copies", [47, 48, 49, 50, 97, 700])
+@pytest.mark.parametrize("where", ["first", "middle", "last"])
+def test_lbvh_runs_of_equal_keys(oracle, gpu_ctx, copies, where):
+    """One triangle many times over (equal keys, ordered by index), at the low end, in the middle and at the high end
+    of the sorted order: the build's short sort orders runs of up to 48 keys that share their upper bits in place
+    and sorts again in full for longer ones; both sides of that limit, and runs that touch the ends of the array."""
+    ntri = 3000
+    xyz, faces = objfmt.random_soup(ntri, seed=77, size=0.004)
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    order = oracle.lbvh_build(xyzw, faces.reshape(-1).astype(np.uint32))["order"]
+    src = int(order[{"first": 0, "middle": ntri // 2, "last": ntri - 1}[where]])
+    rng = np.random.default_rng(copies)
+    dst = rng.choice(np.setdiff1d(np.arange(ntri), [src]), copies - 1, replace=False)
+    faces[dst] = faces[src]
+    idx = faces.reshape(-1).astype(np.uint32)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    _check_lbvh(oracle, scene, xyzw, idx)
+    scene.close()
+
+
 def test_lbvh_structure_large_instanced_scene(oracle, gpu_ctx, bunny_mesh):
     """12 x 12 copies (715 392 triangles: 350 sort tiles on all XCDs, 1 400 refit chunks): sorted
     keys, order, hierarchy and every box against the sequential restatement; then the same after a smaller build has

@@ -1,6 +1,7 @@
 """Random scenes through the GPU LBVH build against the oracle's sequential restatement: sorted keys, order, hierarchy,
 parents and every box, bit for bit.  Sizes around the sort tile (2048 keys) and the refit chunk (512 leaves) come up
-often; some scenes hold exact duplicates (equal Morton keys: the index tie-break) or are flat (one axis without extent).
+often; some scenes hold exact duplicates (equal Morton keys: the index tie-break), one triangle up to 200 times (runs
+of equal keys on both sides of the short sort's limit) or are flat (one axis without extent).
 
     python tools/fuzz_lbvh.py [--scenes 300] [--seed 1] [--max-triangles 60000]
 """
@@ -43,6 +44,11 @@ def main():
             dst = int(rng.integers(0, n - m))
             xyz = xyz.reshape(n, 3, 3)
             xyz[dst:dst + m] = xyz[src:src + m].copy()
+            xyz = xyz.reshape(-1, 3)
+        if rng.random() < 0.25 and n > 300:  # one triangle many times over: a long run of equal keys
+            xyz = xyz.reshape(n, 3, 3)
+            m = int(rng.integers(2, 200))
+            xyz[rng.choice(n, m, replace=False)] = xyz[int(rng.integers(0, n))].copy()
             xyz = xyz.reshape(-1, 3)
         if rng.random() < 0.15:  # a flat scene
             xyz[:, int(rng.integers(0, 3))] = 0.05
