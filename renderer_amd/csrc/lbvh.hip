@@ -5,6 +5,7 @@
 // The build is deterministic: every float that ends up in a node is a min/max of input floats,
 // the sort is stable and the hierarchy depends only on the sorted keys, so the tree is identical
 // on every rank and equal to a sequential restatement of the same steps.
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -17,7 +18,6 @@ namespace {
 constexpr int kSortThreads = 256;
 constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems; // keys per workgroup per pass
-constexpr uint32_t kMaxLevels = 200;                 // refit launches at most (a tree over 63+32-bit keys has under 100 levels)
 
 // ------------------------------------------------------------------------------------------
 // 1. triangle boxes + scene bounds (two-stage min/max reduction, no float atomics)
@@ -408,47 +408,18 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
 }
 
 // ------------------------------------------------------------------------------------------
-// 6. refit, one launch per tree level.  A node is finished in the launch after the one in which
-//    its second child arrived, so every box a launch reads was written by an earlier launch and no
-//    data is handed between workgroups inside a launch; only the arrival counters are shared.
+// 6. refit: the chunks of leaves first, each in LDS, then the nodes that cross chunk boundaries.
 //    Node i (16 floats): child0 lo xyz, hi xyz, child1 lo xyz, hi xyz, child0, child1, first and
 //    last sorted leaf under the node (from the hierarchy kernel's range array).  union_box[i] (8 floats)
 //    carries the node's own box and height upwards.
 // ------------------------------------------------------------------------------------------
-// Appends the flagged lanes' values to a list in global memory.  The list's counter is one address for the whole
-// grid (a few hundred thousand updates of one address take longer than the rest of the refit), so a workgroup of NT
-// threads updates it once for all of its lanes: ballots rank the lanes within a wave, LDS ranks the waves.
-// Call from every thread of the workgroup (three barriers).
-template <int NT>
-__device__ __forceinline__ void block_append(bool flag, uint32_t value, uint32_t* __restrict__ list,
-                                             uint32_t* __restrict__ count) {
-    __shared__ uint32_t s_wave[NT / 64];
-    __shared__ uint32_t s_base;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t mask = __ballot(flag);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < NT / 64; w++) total += s_wave[w];
-        s_base = total ? atomicAdd(count, total) : 0u;
-    }
-    __syncthreads();
-    if (flag) {
-        uint32_t at = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; w++) at += s_wave[w];
-        list[at] = value;
-    }
-    __syncthreads(); // the next call overwrites s_wave
-}
-
-// primitive id -> storage slot, for kernels that know a pixel's winner by its primitive id only
-
 // The fine cut: every subtree (or single leaf) of at most kFineMax leaves whose parent covers more.  These subtrees
 // hold every leaf exactly once; a record is 8 floats, (lo.xyz, first sorted leaf) (hi.xyz, leaf count), the box being
 // the child box the parent's node record carries.  The per-frame binning pass reads them instead of walking the tree.
-// A finished node emits the records of its small children; one counter update per workgroup (see block_append), so
-// the order of the records depends on scheduling: nothing reads them in order.  Call from every thread.
+// A finished node emits the records of its small children; the order of the records depends on scheduling: nothing reads them in order.  The records' counter is one address
+// for the whole grid (a few hundred thousand updates of one address take longer than the rest of the refit), so a
+// workgroup of NT threads updates it once for all of its lanes: ballots rank the lanes within a wave, LDS ranks the
+// waves.  Call from every thread (three barriers).
 template <int NT>
 __device__ __forceinline__ void emit_fine(bool finished, uint32_t c0, uint2 leaves, const float b0[6], const float b1[6],
                                           float* __restrict__ fine, uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
@@ -491,10 +462,19 @@ __device__ __forceinline__ void emit_fine(bool finished, uint32_t c0, uint2 leav
 // LDS, sweep by sweep (a node is finished in the sweep after the one that finished its later child, so the sweep
 // number is the node's height).  What remains are the nodes whose range crosses a chunk boundary (a root-to-leaf path
 // per boundary); the workgroup that owns such a node's index sets its arrival counter to the number of children that
-// are already complete (leaves, and nodes finished inside a chunk) and lists it for the first launch per level if
-// both are.
+// are already complete (leaves, and nodes finished inside a chunk) and puts it in a slot to be climbed from if both
+// are.
 constexpr uint32_t kChunk = 512; // (1024 leaves per workgroup: 12 % slower at five million triangles)
 constexpr uint32_t kOpen = 0xFFFFFFFFu;
+
+// The slot of a node that waits to be climbed from: two per unit of leaves (a chunk, a span), the one for the node
+// that reaches across the unit's lower end and the one for the node that reaches across its upper end (see
+// k_refit_climb); `index` is the node's own, which is one of its leaves'.
+__device__ __forceinline__ uint32_t boundary_slot(uint32_t index, uint2 leaves, uint32_t unit) {
+    const uint32_t u = index / unit;
+    return 2u * u + (leaves.x < u * unit ? 0u : 1u);
+}
+
 
 __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                          const float4* __restrict__ TC, const uint32_t* __restrict__ child,
@@ -502,7 +482,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
                                                          const uint2* __restrict__ range, uint32_t n,
                                                          float* __restrict__ union_box,
                                                          float* __restrict__ nodes, uint32_t* __restrict__ arrive,
-                                                         uint32_t* __restrict__ next, uint32_t* __restrict__ next_count,
+                                                         uint4* __restrict__ slots, uint32_t* __restrict__ root_done,
                                                          uint32_t* __restrict__ finished_count,
                                                          float* __restrict__ fine, uint32_t* __restrict__ fine_count,
                                                          uint32_t fine_cap) {
@@ -586,11 +566,24 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     }
     const uint32_t finished = (uint32_t)__syncthreads_count(valid && !crossing);
     if (t == 0 && finished) atomicAdd(finished_count, finished);
-    block_append<(int)kChunk>(crossing && arrived == 2u, i, next, next_count);
+    // the nodes that are ready to be climbed from, with their links, in the chunk's two slots (see k_refit_climb)
+    __shared__ uint32_t s_taken[2];
+    if (t < 2u) s_taken[t] = 0u;
+    __syncthreads();
+    const bool ready = crossing && arrived == 2u;
+    if (ready) {
+        const uint32_t at = boundary_slot(i, leaves, kChunk);
+        s_taken[at & 1u] = 1u;
+        slots[2 * (size_t)at] = make_uint4(i + 1u, c0, c1, parent[i]);
+        slots[2 * (size_t)at + 1] = make_uint4(leaves.x, leaves.y, 0u, 0u);
+    }
+    __syncthreads();
+    if (t < 2u && !s_taken[t]) slots[2 * (size_t)(2u * blockIdx.x + t)] = make_uint4(0u, 0u, 0u, 0u);
+    if (i == 0u && height != kOpen) *root_done = 1u; // one chunk holds it all
 }
 
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                               const float4* __restrict__ TC, const float* __restrict__ union_box,
+                                               const float4* __restrict__ TC, const float* union_box,
                                                float lo[3], float hi[3], uint32_t& height) {
     if (c & 0x80000000u) {
         uint32_t k = c & 0x7FFFFFFFu;
@@ -603,16 +596,12 @@ __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restr
     }
 }
 
-// Finishes one internal node (both children are complete); returns its parent.
-__device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                               const float4* __restrict__ TC, const uint32_t* __restrict__ child,
-                                               const uint32_t* __restrict__ parent,
-                                               const uint2* __restrict__ range, uint32_t node,
-                                               float* __restrict__ union_box, float* __restrict__ nodes, uint32_t& c0,
-                                               uint2& leaves, float b0[6], float b1[6]) {
-    c0 = child[2 * (size_t)node];
-    const uint32_t c1 = child[2 * (size_t)node + 1];
-    leaves = range[node];
+// Finishes one internal node whose children are both complete: the node's record, and its own box and height for the
+// parent.  The caller brings the node's links (its children and the sorted leaves it covers).
+__device__ __forceinline__ void finish_node(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                            const float4* __restrict__ TC, uint32_t node, uint32_t c0, uint32_t c1,
+                                            uint2 leaves, float* union_box, float* __restrict__ nodes, float b0[6],
+                                            float b1[6]) {
     float l0[3], h0[3], l1[3], h1[3];
     uint32_t ht0, ht1;
     load_child_box(c0, TA, TB, TC, union_box, l0, h0, ht0);
@@ -628,72 +617,99 @@ __device__ __forceinline__ uint32_t refit_node(const float4* __restrict__ TA, co
     u[1] = make_float4(fmaxf(h0[1], h1[1]), fmaxf(h0[2], h1[2]), __uint_as_float(ht), 0.0f);
 #pragma unroll
     for (int a = 0; a < 3; a++) b0[a] = l0[a], b0[3 + a] = h0[a], b1[a] = l1[a], b1[3 + a] = h1[a];
-    return parent[node];
 }
 
-__global__ __launch_bounds__(256) void k_refit_level(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                     const float4* __restrict__ TC, const uint32_t* __restrict__ child,
-                                                     const uint32_t* __restrict__ parent,
-                                                     const uint2* __restrict__ range,
-                                                     const uint32_t* __restrict__ ready,
-                                                     const uint32_t* __restrict__ ready_count,
-                                                     uint32_t* __restrict__ arrive, float* __restrict__ union_box,
-                                                     float* __restrict__ nodes, uint32_t* __restrict__ next,
-                                                     uint32_t* __restrict__ next_count, float* __restrict__ fine,
-                                                     uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
-    // The level's size is read on the device, so the host can queue several levels without waiting for each.
-    const uint32_t nready = *ready_count;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < nready; base += gridDim.x * blockDim.x) { // block-uniform
-        const uint32_t q = base + threadIdx.x;
-        uint32_t up = 0xFFFFFFFFu, c0 = 0;
-        uint2 leaves = make_uint2(0u, 0u);
-        float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0};
-        if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes, c0, leaves, b0, b1);
-        emit_fine<256>(q < nready, c0, leaves, b0, b1, fine, fine_count, fine_cap);
-        // the second child to arrive makes the parent ready for the next launch
-        const bool second = up != 0xFFFFFFFFu && atomicAdd(&arrive[up], 1u) == 1u;
-        block_append<256>(second, up, next, next_count);
-    }
-}
+// The nodes that cross chunk boundaries.  A launch per tree level is mostly launch once a level holds a few hundred
+// nodes, and the top of an unbalanced tree is thirty-odd such levels.  Workgroups climb instead: a lane takes a node
+// that is ready (both children complete), finishes it, counts its arrival at the parent and, if it is the second child
+// to arrive there, goes on with the parent; the first to arrive stops.  The first child's box reaches the second
+// through memory, and that is safe only inside a workgroup: its lanes sit on one CU behind one L1 and one L2, so
+// release and acquire at workgroup scope (the stores have completed before the arrival is counted, the loads are
+// issued after it) are all the ordering it takes, while another workgroup may run behind another XCD's L2.  So the
+// leaves are cut into spans, a workgroup per span: a parent whose leaves all lie in the span gets both arrivals from
+// this workgroup and is climbed into; one that reaches beyond it is handed to the next launch, whose single
+// workgroup has everything for its span.  The parent's links are fetched while the arrival is in flight.
+//
+// Nodes wait in slots: (node + 1, child 0, child 1, parent) (first leaf, last leaf, -, -), node + 1 == 0: empty.  The
+// nodes ready after the chunk kernel cover disjoint stretches of leaves, each with its own index inside and a chunk
+// boundary as well: at most two with their index in one chunk, one across the chunk's lower end and one across its
+// upper end.  Those are the chunk's two slots, and no counter is needed to place them.  The same holds for the nodes
+// handed on, with spans for chunks.  A node is climbed into at most once (only the arrival that finds the counter at 1
+// goes on), whatever the links hold.
+constexpr int kClimbThreads = 1024;
+constexpr uint32_t kSpanChunks = 256; // chunks of leaves per workgroup of the first climb
 
-
-// The long thin top of the tree: once a level holds only a few hundred nodes, a launch per level is mostly launch.
-// One workgroup takes every remaining level in turn, the level's ready list in, the next level's out, a barrier
-// between levels.  It stops at the first empty level; `max_level` bounds the loop whatever the counters hold.
-constexpr int kTailThreads = 1024;
-constexpr uint32_t kTailChunks = 64; // scenes of up to this many refit chunks (32 768 triangles) take it
-__global__ __launch_bounds__(kTailThreads) void k_refit_tail(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                             const float4* __restrict__ TC, const uint32_t* __restrict__ child,
-                                                             const uint32_t* __restrict__ parent,
-                                                             const uint2* __restrict__ range, uint32_t* ready0,
-                                                             uint32_t* ready1, uint32_t* ready_count, uint32_t first_level,
-                                                             uint32_t max_level, uint32_t* __restrict__ arrive,
-                                                             float* union_box, float* __restrict__ nodes,
-                                                             float* __restrict__ fine, uint32_t* __restrict__ fine_count,
-                                                             uint32_t fine_cap) {
-    __shared__ uint32_t s_nready;
-    for (uint32_t level = first_level; level < max_level; level++) { // block-uniform
-        if (threadIdx.x == 0) s_nready = __hip_atomic_load(ready_count + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const uint32_t nready = s_nready;
-        if (nready == 0) break;
-        const uint32_t* ready = (level & 1u) ? ready1 : ready0;
-        uint32_t* next = (level & 1u) ? ready0 : ready1;
-        for (uint32_t base = 0; base < nready; base += (uint32_t)kTailThreads) { // block-uniform
-            const uint32_t q = base + threadIdx.x;
-            uint32_t up = 0xFFFFFFFFu, c0 = 0;
-            uint2 leaves = make_uint2(0u, 0u);
-            float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0};
-            if (q < nready) up = refit_node(TA, TB, TC, child, parent, range, ready[q], union_box, nodes, c0, leaves, b0, b1);
-            emit_fine<kTailThreads>(q < nready, c0, leaves, b0, b1, fine, fine_count, fine_cap);
-            const bool second = up != 0xFFFFFFFFu && atomicAdd(&arrive[up], 1u) == 1u;
-            block_append<kTailThreads>(second, up, next, ready_count + level + 1);
+__global__ __launch_bounds__(kClimbThreads) void k_refit_climb(const float4* __restrict__ TA, const float4* __restrict__ TB,
+                                                               const float4* __restrict__ TC, const uint32_t* __restrict__ child,
+                                                               const uint32_t* __restrict__ parent,
+                                                               const uint2* __restrict__ range, const uint4* __restrict__ slots,
+                                                               uint32_t nslots, uint32_t slots_per_group, uint32_t span,
+                                                               uint4* __restrict__ handed, uint32_t* arrive, float* union_box,
+                                                               float* __restrict__ nodes, uint32_t* __restrict__ finished_count,
+                                                               uint32_t* __restrict__ root_done,
+                                                               float* __restrict__ fine, uint32_t* __restrict__ fine_count,
+                                                               uint32_t fine_cap) {
+    // span == 0: one workgroup, every leaf is its own
+    const uint32_t first = blockIdx.x * slots_per_group, last = min(first + slots_per_group, nslots);
+    const uint32_t span_lo = blockIdx.x * span, span_hi = span ? span_lo + (span - 1u) : 0xFFFFFFFFu;
+    uint32_t finished = 0;
+    for (uint32_t q = first + threadIdx.x; q < last; q += (uint32_t)kClimbThreads) {
+        const uint4 e0 = slots[2 * (size_t)q], e1 = slots[2 * (size_t)q + 1];
+        if (e0.x == 0u) continue;
+        uint32_t node = e0.x - 1u, up = e0.w;
+        uint2 c = make_uint2(e0.y, e0.z), leaves = make_uint2(e1.x, e1.y);
+        for (;;) {
+            float b0[6], b1[6];
+            finish_node(TA, TB, TC, node, c.x, c.y, leaves, union_box, nodes, b0, b1);
+            finished++;
+            // the node's records for the fine cut (few up here: a counter update each)
+            if (leaves.y - leaves.x + 1u > kFineMax) {
+                const uint32_t gamma = c.x & 0x7FFFFFFFu;
+                const uint32_t n0 = gamma - leaves.x + 1u, n1 = leaves.y - gamma;
+                if (n0 <= kFineMax) {
+                    const uint32_t at = atomicAdd(fine_count, 1u);
+                    if (at < fine_cap) {
+                        float4* r = (float4*)fine + 2 * (size_t)at;
+                        r[0] = make_float4(b0[0], b0[1], b0[2], __uint_as_float(leaves.x));
+                        r[1] = make_float4(b0[3], b0[4], b0[5], __uint_as_float(n0));
+                    }
+                }
+                if (n1 <= kFineMax) {
+                    const uint32_t at = atomicAdd(fine_count, 1u);
+                    if (at < fine_cap) {
+                        float4* r = (float4*)fine + 2 * (size_t)at;
+                        r[0] = make_float4(b1[0], b1[1], b1[2], __uint_as_float(gamma + 1u));
+                        r[1] = make_float4(b1[3], b1[4], b1[5], __uint_as_float(n1));
+                    }
+                }
+            }
+            if (up == 0xFFFFFFFFu) { // the root
+                *root_done = 1u;
+                break;
+            }
+            node = up;
+            // (these three arrays were written by an earlier launch: nothing here orders them)
+            c = ((const uint2*)child)[node];
+            leaves = range[node];
+            up = parent[node];
+            // The counter is shared with other workgroups when the parent reaches beyond the span (device scope, and
+            // nothing is read on the strength of it before the next launch); inside the span both arrivals are this
+            // workgroup's, and the fences on either side of it order the box behind the first and before the second.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const uint32_t before = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (before != 1u) break;
+            if (leaves.x < span_lo || leaves.y > span_hi) { // (never with span == 0)
+                const uint32_t at = boundary_slot(node, leaves, span);
+                handed[2 * (size_t)at] = make_uint4(node + 1u, c.x, c.y, up);
+                handed[2 * (size_t)at + 1] = make_uint4(leaves.x, leaves.y, 0u, 0u);
+                break;
+            }
         }
-        // One workgroup, one CU: what it stored is read back through the same L1 and L2, so the barrier (which waits
-        // for the stores) is all the ordering the next level needs.  (A device-scope fence here writes the whole L2
-        // back, tens of microseconds per level behind the chunk refit's half gigabyte of nodes.)
-        __syncthreads();
     }
+    // the count the host checks the tree by: one update per wave
+    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off);
+    if ((threadIdx.x & 63u) == 0u && finished) atomicAdd(finished_count, finished);
 }
 
 
@@ -728,23 +744,23 @@ __device__ __forceinline__ uint32_t block_ranks(bool f0, bool f1, uint32_t (*tot
     return all0 + all1;
 }
 
-// The host queues this kernel behind the refit launches without knowing whether they were enough: `pending` is the
-// size of the level after the last one queued, and while that is not zero the node records are not complete and
-// nothing is read.  summary: [0] number of cut records (kCutUnfinished: refit not finished), [1..6] scene bounds,
+// The host queues this kernel behind the refit without knowing whether it reached the root: while `root_done` is
+// zero the node records are not complete and nothing is read.  summary: [0] number of cut records (kCutUnfinished: refit not finished), [1..6] scene bounds,
 // [7] height of the root -- everything the host wants to know at the end of a build, in one place.
 constexpr uint32_t kCutUnfinished = 0xFFFFFFFFu;
-constexpr uint32_t kSummaryWords = 12; // [8]: records of the fine cut (counted by the refit kernels)
+constexpr uint32_t kSummaryWords = 8;
 
 __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restrict__ nodes, float* __restrict__ cut,
                                                           float* __restrict__ groups,
-                                                          const uint32_t* __restrict__ pending,
+                                                          const uint32_t* __restrict__ root_done,
+                                                          const uint32_t* __restrict__ unsorted,
                                                           const float* __restrict__ bbox,
                                                           const float* __restrict__ union_box,
                                                           uint32_t* __restrict__ summary) {
     __shared__ uint32_t frontier[2][kCutCap]; // (parent << 1) | side
     __shared__ uint32_t tot[2][kCutThreads / 64];
     const uint32_t tid = threadIdx.x;
-    if (*pending != 0u) { // block-uniform
+    if (*root_done == 0u || *unsorted != 0u) { // block-uniform (unsorted: the sort gave up, the tree is not to be read)
         if (tid == 0) summary[0] = kCutUnfinished;
         return;
     }
@@ -835,6 +851,16 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
 static uint32_t fine_cap_for(uint32_t n) { return (uint32_t)std::min<uint64_t>(n, (uint64_t)n * 5u / (2u * kFineMax) + 1024u); }
 static uint32_t bounds_blocks_for(uint32_t n) { return std::min<uint32_t>((n + 255) / 256, 1024); }
 static uint32_t sort_tiles_for(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+static uint32_t refit_chunks_for(uint32_t n) { return (n + kChunk - 1) / kChunk; }
+static uint32_t refit_spans_for(uint32_t n) { return (refit_chunks_for(n) + kSpanChunks - 1) / kSpanChunks; }
+// The build's counters, each in a stretch of memory of its own (updates of one address take their turns, and so do
+// updates of neighbouring addresses: ten thousand workgroups adding to two counters in one 64-byte line took longer
+// than the rest of the chunk kernel), then the summary the cut kernel writes; one copy fetches them all.
+constexpr uint32_t kWordStride = 64;
+enum : uint32_t { kWFinishedChunks = 0, kWFinishedClimb = kWordStride, kWRootDone = 2 * kWordStride, kWFineCount = 3 * kWordStride,
+                  kWUnsorted = 4 * kWordStride, kWSummary = 5 * kWordStride, kWords = 5 * kWordStride + 16 };
+static_assert(kSummaryWords <= 16, "the summary has sixteen words");
+static size_t build_words_for(uint32_t n) { return kWords + (size_t)refit_spans_for(n) * 2 * 8; }
 
 size_t lbvh_keep_bytes(uint32_t n) {
     if (n < 2) return 0;
@@ -850,8 +876,8 @@ size_t lbvh_scratch_bytes(uint32_t n) {
     if (n < 2) return 0;
     const size_t ntiles = sort_tiles_for(n);
     const size_t sizes[] = {(size_t)bounds_blocks_for(n) * 24, 32, (size_t)n * 8, (size_t)n * 4, ntiles * 256 * 4,
-                            (size_t)(n - 1) * 4, (ntiles * 256 / kScanBlock + 2) * 4, (size_t)(n - 1) * 4,
-                            (size_t)(n - 1) * 4, (kMaxLevels + 2 + kSummaryWords) * 4, (size_t)(n - 1) * 32, (size_t)(n - 1) * 8};
+                            (size_t)(n - 1) * 4, (ntiles * 256 / kScanBlock + 2) * 4, (size_t)refit_chunks_for(n) * 64,
+                            build_words_for(n) * 4, (size_t)(n - 1) * 32, (size_t)(n - 1) * 8};
     size_t total = 0;
     for (size_t b : sizes) total += Arena::aligned(b);
     return total;
@@ -882,9 +908,12 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     uint32_t* counts = tmp.take<uint32_t>((size_t)ntiles * 256 * 4);
     uint32_t* arrive = tmp.take<uint32_t>((size_t)(n - 1) * 4);
     uint32_t* scan_totals = tmp.take<uint32_t>(((size_t)ntiles * 256 / kScanBlock + 2) * 4);
-    uint32_t* ready[2] = {tmp.take<uint32_t>((size_t)(n - 1) * 4), tmp.take<uint32_t>((size_t)(n - 1) * 4)};
-    // one counter per tree level, one for the chunks, and the build's summary behind them (one copy fetches it all)
-    uint32_t* ready_count = tmp.take<uint32_t>((kMaxLevels + 2 + kSummaryWords) * 4);
+    const uint32_t nchunks = refit_chunks_for(n), nspans = refit_spans_for(n);
+    uint4* slots = tmp.take<uint4>((size_t)nchunks * 64); // two per chunk (see k_refit_climb)
+    // the counters and the summary, and behind them the slots of the nodes handed from the first climb to the second,
+    // two per span; all zero to begin with
+    uint32_t* words = tmp.take<uint32_t>(build_words_for(n) * 4);
+    uint4* const handed = (uint4*)(words + kWords);
     float* union_box = tmp.take<float>((size_t)(n - 1) * 32);
     uint2* range = tmp.take<uint2>((size_t)(n - 1) * 8);
     // what the scene keeps
@@ -905,8 +934,8 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
 
     const float4* T0 = (const float4*)records;
     const dim3 blk(256), grid_n((n + 255) / 256);
-    HIP_RET(hipMemsetAsync(ready_count, 0, (kMaxLevels + 2 + kSummaryWords) * 4, s));
-    uint32_t* const too_long = ready_count + kMaxLevels + 2 + 9; // summary word 9
+    HIP_RET(hipMemsetAsync(words, 0, build_words_for(n) * 4, s));
+    uint32_t* const too_long = words + kWUnsorted;
     hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_blocks), blk, 0, s, T0, n, partial);
     hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, bounds_blocks, d_bbox);
     hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, n, d_bbox, sc.morton, sc.order);
@@ -937,58 +966,35 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     hipLaunchKernelGGL(k_permute, dim3(xcd_grid((n + 255) / 256)), blk, 0, s, T0, sc.order, n, A1, B1, C1, sc.slot_of);
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
-    uint32_t* finished_in_chunks = ready_count + kMaxLevels + 1;
-    uint32_t* fine_count = ready_count + kMaxLevels + 2 + 8;
-    const uint32_t nchunks = (n + kChunk - 1) / kChunk;
+    uint32_t* fine_count = words + kWFineCount;
     hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, (const float4*)A1, (const float4*)B1,
-                       (const float4*)C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, ready[0], ready_count,
-                       finished_in_chunks, sc.fine, fine_count, fine_cap);
+                       (const float4*)C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
+                       words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
+    // the nodes that cross chunk boundaries: a workgroup per span of chunks as far as the spans go, one for the rest
+    if (nspans > 1)
+        hipLaunchKernelGGL(k_refit_climb, dim3(nspans), dim3(kClimbThreads), 0, s, (const float4*)A1, (const float4*)B1,
+                           (const float4*)C1, sc.child, sc.parent, range, (const uint4*)slots, 2u * nchunks, 2u * kSpanChunks,
+                           kSpanChunks * kChunk, handed, arrive, union_box, sc.nodes, words + kWFinishedClimb, words + kWRootDone,
+                           sc.fine, fine_count, fine_cap);
+    if (nchunks > 1)
+        hipLaunchKernelGGL(k_refit_climb, dim3(1), dim3(kClimbThreads), 0, s, (const float4*)A1, (const float4*)B1,
+                           (const float4*)C1, sc.child, sc.parent, range, (const uint4*)(nspans > 1 ? handed : slots),
+                           2u * (nspans > 1 ? nspans : nchunks), 2u * (nspans > 1 ? nspans : nchunks), 0u, (uint4*)nullptr, arrive,
+                           union_box, sc.nodes, words + kWFinishedClimb, words + kWRootDone, sc.fine, fine_count, fine_cap);
+    hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
+                       (const uint32_t*)(words + kWRootDone), (const uint32_t*)too_long, (const float*)d_bbox,
+                       (const float*)union_box, words + kWSummary);
     HIP_RET(hipGetLastError());
-    // The nodes that cross chunk boundaries: one launch per tree level; level L reads its size from ready_count[L] on
-    // the device and appends the nodes that become ready to level L + 1.  The host does not know the tree's height:
-    // it queues as many levels as a tree of this size usually has and the cut kernel behind them (an empty launch
-    // costs a twentieth of a look at the counters), then looks once; the rare deeper tree gets sixteen more levels
-    // and another cut.
-    const dim3 grid_level(std::min<uint32_t>(nchunks, 2048));
-    uint32_t host_words[kMaxLevels + 2 + kSummaryWords] = {0};
-    const uint32_t* level_count = host_words;
-    const uint32_t* summary = host_words + kMaxLevels + 2;
-    uint32_t log2n = 0;
-    while ((1ull << log2n) < n) log2n++;
-    uint32_t level = 0, want = nchunks > 1 ? std::min<uint32_t>(kMaxLevels, log2n + 14u) : 0u;
-    // Small scenes: every level holds a handful of nodes, and twenty-odd launches (most of them empty: the host queues
-    // them without knowing the height) cost more than one workgroup that takes the levels in turn (0.32 -> 0.30 ms for
-    // the bunny).  Not so for large ones: a level of a thousand nodes is a chain of six dependent round trips either
-    // way, and a launch per level runs the wide levels on the whole GPU (5 M triangles: 1.6 ms against 2.9 ms).
-    if (nchunks > 1 && nchunks <= kTailChunks) {
-        hipLaunchKernelGGL(k_refit_tail, dim3(1), dim3(kTailThreads), 0, s, (const float4*)A1, (const float4*)B1,
-                           (const float4*)C1, sc.child, sc.parent, range, ready[0], ready[1], ready_count, 0u, kMaxLevels,
-                           arrive, union_box, sc.nodes, sc.fine, fine_count, fine_cap);
-        level = want = kMaxLevels; // the cut kernel looks at the counter behind the last level
-    }
-    for (;;) {
-        for (; level < want; level++) {
-            const int cur = (int)(level & 1u);
-            hipLaunchKernelGGL(k_refit_level, grid_level, blk, 0, s, (const float4*)A1, (const float4*)B1,
-                               (const float4*)C1, sc.child, sc.parent, range, ready[cur], ready_count + level, arrive, union_box,
-                               sc.nodes, ready[cur ^ 1], ready_count + level + 1, sc.fine, fine_count, fine_cap);
-        }
-        hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
-                           (const uint32_t*)(ready_count + level), (const float*)d_bbox, (const float*)union_box,
-                           ready_count + kMaxLevels + 2);
-        HIP_RET(hipGetLastError());
-        HIP_RET(hipMemcpyAsync(host_words, ready_count, sizeof host_words, hipMemcpyDeviceToHost, s));
-        HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
-        if (short_sort && summary[9] != 0u) return hipErrorNotReady; // the caller sorts again with all eight passes
-        if (level_count[level] == 0) break; // nothing is waiting for another level
-        if (level >= kMaxLevels) return hipErrorUnknown; // a tree over 63+32-bit keys is at most 96 levels deep
-        want = std::min<uint32_t>(kMaxLevels, level + 16u);
-    }
-    uint64_t finished = level_count[kMaxLevels + 1];
-    for (uint32_t l = 0; l < level; l++) finished += level_count[l];
-    if (finished != n - 1 || summary[0] == kCutUnfinished) return hipErrorUnknown; // every internal node must have been refitted
+    uint32_t host_words[kWords] = {0};
+    const uint32_t* summary = host_words + kWSummary;
+    HIP_RET(hipMemcpyAsync(host_words, words, sizeof host_words, hipMemcpyDeviceToHost, s));
+    HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
+    if (short_sort && host_words[kWUnsorted] != 0u) return hipErrorNotReady; // the caller sorts again with all eight passes
+    const uint64_t finished = (uint64_t)host_words[kWFinishedChunks] + host_words[kWFinishedClimb];
+    if (finished != n - 1 || host_words[kWRootDone] == 0u || summary[0] == kCutUnfinished) return hipErrorUnknown; // every internal node must have been refitted
     sc.ncut = summary[0];
-    sc.nfine = summary[8] <= fine_cap ? summary[8] : 0u; // more than the array holds: no fine cut
+    const uint32_t nfine = host_words[kWFineCount];
+    sc.nfine = nfine <= fine_cap ? nfine : 0u; // more than the array holds: no fine cut
     std::memcpy(sc.bbox, summary + 1, 24);
     sc.height = summary[7];
     sc.has_bvh = true;

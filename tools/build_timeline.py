@@ -20,7 +20,7 @@ t0 = int(rows[s]["Start_Timestamp"])
 groups = {}
 for r in rows[s:]:
     n = short(r["Kernel_Name"])
-    if n.startswith("k_render"):
+    if n.startswith(("k_render", "k_scatter", "k_vis_fill", "k_bin")):  # the first draw: the build is over
         break
     a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if "-v" in sys.argv:
