@@ -509,6 +509,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         // with a tree the assembled triangles are scratch: the build stores them again in Morton order
         // (as 48-byte records: the gather into Morton order then pulls one or two cache lines per triangle, not three)
         float* records = tree ? scratch.take<float>((size_t)d.ntri * 48) : nullptr;
+        float* bounds = tree ? lbvh_take_bounds(scratch, d.ntri) : nullptr;
         float* A0 = tree ? records : d.triA;
         float* B0 = tree ? records + 4 : d.triB;
         float* C0 = tree ? records + 8 : d.triC;
@@ -518,9 +519,9 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
             if ((e = hipMemcpyAsync(d_tr, translations_xyz, (size_t)ninst * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
                 return bail(e, "hipMemcpyAsync(translations)");
         }
-        if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0, tree ? 3u : 1u)) != hipSuccess)
+        if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0, tree ? 3u : 1u, bounds)) != hipSuccess)
             return bail(e, "assemble kernel");
-        if ((e = build_lbvh(ctx->stream, d, keep, scratch, records)) != hipSuccess) return bail(e, "LBVH build");
+        if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
     ctx->live_scenes++;

@@ -116,8 +116,12 @@ hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, c
                                 float* color3);
 // Triangle g's three 16-byte items go to A[g * stride], B[g * stride], C[g * stride] (in float4 units): stride 1
 // fills three arrays, stride 3 with B = A + 4 floats and C = A + 8 floats one array of 48-byte records.
+// `bounds` (or null): bounds_blocks_for(triangles) entries of six floats, the box of a share of the triangles each
+// (lo xyz, hi xyz), for build_lbvh.
+inline uint32_t bounds_blocks_for(uint32_t n) { return n / 256u + 1u < 2048u ? n / 256u + 1u : 2048u; }
 hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
-                           const float* translations, uint32_t ninst, float* A, float* B, float* C, uint32_t stride);
+                           const float* translations, uint32_t ninst, float* A, float* B, float* C, uint32_t stride,
+                           float* bounds);
 hipError_t launch_render_brute(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out);
 // Device memory for the bins of a frame's binning pass: `nbins` counters, then `nbins` lists of 256 entries.  The
 // counters are zero between draws (whoever allocates the memory clears all of it once; every traced block leaves
@@ -161,6 +165,8 @@ hipError_t launch_deinterleave(hipStream_t s, const FrameK& f, const uint32_t* g
 // `keep`, temporaries from `scratch` (sizes from the two functions below).  Synchronises the stream once at the end.
 size_t lbvh_keep_bytes(uint32_t ntri);
 size_t lbvh_scratch_bytes(uint32_t ntri);
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* records);
+// `bounds`: what launch_assemble left for these records, in memory from lbvh_take_bounds (part of the scratch bytes).
+float* lbvh_take_bounds(Arena& scratch, uint32_t n);
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* records, const float* bounds);
 
 } // namespace inv

@@ -22,13 +22,6 @@ constexpr int kSortTile = kSortThreads * kSortItems; // keys per workgroup per p
 // ------------------------------------------------------------------------------------------
 // 1. triangle boxes + scene bounds (two-stage min/max reduction, no float atomics)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tri_box(const float4& A, const float4& B, const float4& C, float lo[3], float hi[3]) {
-    float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
-    float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
-    lo[0] = fminf(A.x, fminf(bx, cx)), lo[1] = fminf(A.y, fminf(by, cy)), lo[2] = fminf(A.z, fminf(bz, cz));
-    hi[0] = fmaxf(A.x, fmaxf(bx, cx)), hi[1] = fmaxf(A.y, fmaxf(by, cy)), hi[2] = fmaxf(A.z, fmaxf(bz, cz));
-}
-
 // Workgroups go to the eight XCDs in turn, each with an L2 of its own.  Where neighbouring blocks of work touch
 // neighbouring memory, XCD x takes the x-th eighth of the blocks instead of every eighth block: launch
 // xcd_grid(nblocks) workgroups and leave if xcd_block() is not below nblocks.
@@ -37,52 +30,16 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks) {
 }
 static inline uint32_t xcd_grid(uint32_t nblocks) { return ((nblocks + 7u) >> 3) * 8u; }
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// partial[block][6] = lo xyz, hi xyz over the block's triangles (grid-stride)
-// (the assembled triangles come as 48-byte records: T[3 i], T[3 i + 1], T[3 i + 2])
-__global__ __launch_bounds__(256) void k_bounds_partial(const float4* __restrict__ T, uint32_t n,
-                                                        float* __restrict__ partial) {
-    __shared__ float red[4][6];
+// The scene bounds from their first stage: partial[block][6] = lo xyz, hi xyz over a share of the triangles, which
+// the assembly kernel leaves on its way (no float atomics).
+__global__ __launch_bounds__(1024) void k_bounds_final(const float* __restrict__ partial, uint32_t nblocks,
+                                                       float* __restrict__ bbox) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float l[3], h[3];
-        tri_box(T[3 * (size_t)i], T[3 * (size_t)i + 1], T[3 * (size_t)i + 2], l, h);
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 1024u) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], l[a]), hi[a] = fmaxf(hi[a], h[a]);
+        for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], partial[b * 6 + a]), hi[a] = fmaxf(hi[a], partial[b * 6 + 3 + a]);
     }
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        float l = wave_min(lo[a]), h = wave_max(hi[a]);
-        if (lane == 0) red[wave][a] = l, red[wave][3 + a] = h;
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        float v = red[0][threadIdx.x];
-        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
-        partial[blockIdx.x * 6 + threadIdx.x] = v;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_bounds_final(const float* __restrict__ partial, uint32_t nblocks,
-                                                     float* __restrict__ bbox) {
-    int lane = threadIdx.x;
-    for (int a = 0; a < 6; a++) {
-        float v = a < 3 ? INFINITY : -INFINITY;
-        for (uint32_t b = lane; b < nblocks; b += 64) v = a < 3 ? fminf(v, partial[b * 6 + a]) : fmaxf(v, partial[b * 6 + a]);
-        v = a < 3 ? wave_min(v) : wave_max(v);
-        if (lane == 0) bbox[a] = v;
-    }
+    block_bounds<1024>(lo, hi, bbox);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -849,7 +806,6 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
 // leaves under larger parents; badly unbalanced trees have up to n.  A build that needs more than this leaves the
 // scene without a fine cut (its draws then start from the coarse cut, as scenes of a few triangles do).
 static uint32_t fine_cap_for(uint32_t n) { return (uint32_t)std::min<uint64_t>(n, (uint64_t)n * 5u / (2u * kFineMax) + 1024u); }
-static uint32_t bounds_blocks_for(uint32_t n) { return std::min<uint32_t>((n + 255) / 256, 1024); }
 static uint32_t sort_tiles_for(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 static uint32_t refit_chunks_for(uint32_t n) { return (n + kChunk - 1) / kChunk; }
 static uint32_t refit_spans_for(uint32_t n) { return (refit_chunks_for(n) + kSpanChunks - 1) / kSpanChunks; }
@@ -883,25 +839,28 @@ size_t lbvh_scratch_bytes(uint32_t n) {
     return total;
 }
 
-static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, bool short_sort);
+static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
+                                  const float* bounds, bool short_sort);
 
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records) {
+float* lbvh_take_bounds(Arena& tmp, uint32_t n) { return n < 2 ? nullptr : tmp.take<float>((size_t)bounds_blocks_for(n) * 24); }
+
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, const float* bounds) {
     const size_t keep_used = keep.used, tmp_used = tmp.used;
-    hipError_t e = build_lbvh_with(s, sc, keep, tmp, records, true);
+    hipError_t e = build_lbvh_with(s, sc, keep, tmp, records, bounds, true);
     if (e == hipErrorNotReady) { // long runs of keys that agree in their upper bits (repeated triangles): all eight passes
         keep.used = keep_used, tmp.used = tmp_used;
-        e = build_lbvh_with(s, sc, keep, tmp, records, false);
+        e = build_lbvh_with(s, sc, keep, tmp, records, bounds, false);
     }
     return e;
 }
 
-static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, bool short_sort) {
+static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
+                                  const float* bounds, bool short_sort) {
     const uint32_t n = sc.ntri;
     sc.has_bvh = false;
     if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
     const uint32_t bounds_blocks = bounds_blocks_for(n);
     const uint32_t ntiles = sort_tiles_for(n);
-    float* partial = tmp.take<float>((size_t)bounds_blocks * 24);
     float* d_bbox = tmp.take<float>(32);
     uint64_t* keys_alt = tmp.take<uint64_t>((size_t)n * 8);
     uint32_t* vals_alt = tmp.take<uint32_t>((size_t)n * 4);
@@ -936,8 +895,7 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     const dim3 blk(256), grid_n((n + 255) / 256);
     HIP_RET(hipMemsetAsync(words, 0, build_words_for(n) * 4, s));
     uint32_t* const too_long = words + kWUnsorted;
-    hipLaunchKernelGGL(k_bounds_partial, dim3(bounds_blocks), blk, 0, s, T0, n, partial);
-    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial, bounds_blocks, d_bbox);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(1024), 0, s, bounds, bounds_blocks, d_bbox);
     hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, n, d_bbox, sc.morton, sc.order);
     // 63 significant key bits -> 8 passes; an even number of passes leaves the result in sc.morton / sc.order.  The
     // short form: the upper five digits only (an odd number: the result is in the other pair of arrays), then

@@ -187,6 +187,45 @@ __device__ __forceinline__ void mt_test(const FrameK& f, const Ray& r, const flo
     best.slot = slot;
 }
 
+// Box of a triangle record as stored (A, B = v1 - A, C = v2 - A): the corners are A, A + B, A + C, not the vertices
+// they were made from.
+__device__ __forceinline__ void tri_box(const float4& A, const float4& B, const float4& C, float lo[3], float hi[3]) {
+    float bx = A.x + B.x, by = A.y + B.y, bz = A.z + B.z;
+    float cx = A.x + C.x, cy = A.y + C.y, cz = A.z + C.z;
+    lo[0] = fminf(A.x, fminf(bx, cx)), lo[1] = fminf(A.y, fminf(by, cy)), lo[2] = fminf(A.z, fminf(bz, cz));
+    hi[0] = fmaxf(A.x, fmaxf(bx, cx)), hi[1] = fmaxf(A.y, fmaxf(by, cy)), hi[2] = fmaxf(A.z, fmaxf(bz, cz));
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// The box over the boxes of all lanes of a workgroup of NT threads, to out[0..5] (lo xyz, hi xyz).  Call from every
+// thread (one barrier); not twice in a row without a barrier in between.
+template <int NT>
+__device__ __forceinline__ void block_bounds(const float lo[3], const float hi[3], float* __restrict__ out) {
+    __shared__ float red[NT / 64][6];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float l = wave_min(lo[a]), h = wave_max(hi[a]);
+        if (lane == 0) red[wave][a] = l, red[wave][3 + a] = h;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < NT / 64; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        out[threadIdx.x] = v;
+    }
+}
+
 __device__ __forceinline__ Hit miss_hit() {
     Hit h;
     h.key = kMissKey;
