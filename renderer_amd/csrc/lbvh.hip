@@ -260,9 +260,6 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// 4. gather the triangle records into sorted order
-// ------------------------------------------------------------------------------------------
 // The short form of the sort: five passes order the keys by their upper 40 bits (stably, so keys that agree there stay
 // in index order); what is left is to order every run of keys with equal upper bits by the lower 24.  Such runs are
 // triangles whose box centres share a cell of 1/8192 of the scene's extent per axis: one or a few, unless triangles
@@ -294,18 +291,6 @@ __global__ __launch_bounds__(256) void k_sort_runs(const uint64_t* __restrict__ 
         at = a + before;
     }
     kout[at] = k, vout[at] = vin[i];
-}
-
-__global__ __launch_bounds__(256) void k_permute(const float4* __restrict__ T, const uint32_t* __restrict__ order,
-                                                 uint32_t n, float4* __restrict__ A1, float4* __restrict__ B1,
-                                                 float4* __restrict__ C1, uint32_t* __restrict__ slot_of) {
-    // (neighbours in Morton order are neighbours in space and often in the input: one L2 for a stretch of them)
-    uint32_t i = xcd_block((n + 255u) / 256u) * 256u + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s = order[i];
-    const float4* rec = T + 3 * (size_t)s;
-    A1[i] = rec[0], B1[i] = rec[1], C1[i] = rec[2];
-    slot_of[s] = i; // the inverse of `order`: primitive id -> sorted position
 }
 
 // ------------------------------------------------------------------------------------------
@@ -433,8 +418,10 @@ __device__ __forceinline__ uint32_t boundary_slot(uint32_t index, uint2 leaves, 
 }
 
 
-__global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restrict__ TA, const float4* __restrict__ TB,
-                                                         const float4* __restrict__ TC, const uint32_t* __restrict__ child,
+__global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restrict__ T0, const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ slot_of, float4* __restrict__ TA,
+                                                         float4* __restrict__ TB, float4* __restrict__ TC,
+                                                         const uint32_t* __restrict__ child,
                                                          const uint32_t* __restrict__ parent,
                                                          const uint2* __restrict__ range, uint32_t n,
                                                          float* __restrict__ union_box,
@@ -446,10 +433,19 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     __shared__ float s_leaf[6][kChunk]; // boxes of the chunk's leaves
     __shared__ float s_box[6][kChunk];  // boxes of the internal nodes finished here
     __shared__ uint32_t s_sweep[kChunk]; // sweep that finished the node, kOpen while it waits
-    const uint32_t t = threadIdx.x, base = blockIdx.x * kChunk, i = base + t;
+    const uint32_t chunk = blockIdx.x; // (taking the chunks XCD by XCD instead makes no difference)
+    const uint32_t t = threadIdx.x, base = chunk * kChunk, i = base + t;
     if (i < n) {
+        // The gather into sorted order happens here, on the way: the triangle at sorted position i is the assembled
+        // record order[i].  (A kernel of its own for it read the records, wrote them sorted, and this one read them
+        // again: a sixth of a five-million-triangle build.)
+        const uint32_t src = order[i];
+        const float4* rec = T0 + 3 * (size_t)src;
+        const float4 a = rec[0], b = rec[1], c = rec[2];
+        TA[i] = a, TB[i] = b, TC[i] = c;
+        slot_of[src] = i; // the inverse of `order`: primitive id -> sorted position
         float lo[3], hi[3];
-        tri_box(TA[i], TB[i], TC[i], lo, hi);
+        tri_box(a, b, c, lo, hi);
 #pragma unroll
         for (int a = 0; a < 3; a++) s_leaf[a][t] = lo[a], s_leaf[3 + a][t] = hi[a];
     }
@@ -535,7 +531,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
         slots[2 * (size_t)at + 1] = make_uint4(leaves.x, leaves.y, 0u, 0u);
     }
     __syncthreads();
-    if (t < 2u && !s_taken[t]) slots[2 * (size_t)(2u * blockIdx.x + t)] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < 2u && !s_taken[t]) slots[2 * (size_t)(2u * chunk + t)] = make_uint4(0u, 0u, 0u, 0u);
     if (i == 0u && height != kOpen) *root_done = 1u; // one chunk holds it all
 }
 
@@ -921,12 +917,11 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
         std::swap(vin, vout);
     }
     if (short_sort) hipLaunchKernelGGL(k_sort_runs, grid_n, blk, 0, s, (const uint64_t*)kin, (const uint32_t*)vin, n, kout, vout, too_long);
-    hipLaunchKernelGGL(k_permute, dim3(xcd_grid((n + 255) / 256)), blk, 0, s, T0, sc.order, n, A1, B1, C1, sc.slot_of);
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     uint32_t* fine_count = words + kWFineCount;
-    hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, (const float4*)A1, (const float4*)B1,
-                       (const float4*)C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
+    hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, (const uint32_t*)sc.order, sc.slot_of, A1, B1,
+                       C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
                        words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
     // the nodes that cross chunk boundaries: a workgroup per span of chunks as far as the spans go, one for the rest
     if (nspans > 1)
