@@ -535,18 +535,22 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     if (i == 0u && height != kOpen) *root_done = 1u; // one chunk holds it all
 }
 
+// The box and height of a child: a leaf's from its triangle, a node's from what the node left in union_box.  The
+// lanes of a wave climb chains of their own and meet leaves and nodes in any mix, so both kinds of loads are issued
+// for every lane (from element 0 where they do not apply) and the result is picked afterwards: one wait for memory
+// per child instead of one per kind.
 __device__ __forceinline__ void load_child_box(uint32_t c, const float4* __restrict__ TA, const float4* __restrict__ TB,
                                                const float4* __restrict__ TC, const float* union_box,
                                                float lo[3], float hi[3], uint32_t& height) {
-    if (c & 0x80000000u) {
-        uint32_t k = c & 0x7FFFFFFFu;
-        tri_box(TA[k], TB[k], TC[k], lo, hi);
-        height = 0;
-    } else {
-        const float4 a = ((const float4*)union_box)[2 * (size_t)c], b = ((const float4*)union_box)[2 * (size_t)c + 1];
-        lo[0] = a.x, lo[1] = a.y, lo[2] = a.z, hi[0] = a.w, hi[1] = b.x, hi[2] = b.y;
-        height = __float_as_uint(b.z);
-    }
+    const bool leaf = (c & 0x80000000u) != 0u;
+    const uint32_t k = c & 0x7FFFFFFFu, kt = leaf ? k : 0u, kn = leaf ? 0u : k;
+    const float4 ta = TA[kt], tb = TB[kt], tc = TC[kt];
+    const float4 a = ((const float4*)union_box)[2 * (size_t)kn], b = ((const float4*)union_box)[2 * (size_t)kn + 1];
+    float tlo[3], thi[3];
+    tri_box(ta, tb, tc, tlo, thi);
+    lo[0] = leaf ? tlo[0] : a.x, lo[1] = leaf ? tlo[1] : a.y, lo[2] = leaf ? tlo[2] : a.z;
+    hi[0] = leaf ? thi[0] : a.w, hi[1] = leaf ? thi[1] : b.x, hi[2] = leaf ? thi[2] : b.y;
+    height = leaf ? 0u : __float_as_uint(b.z);
 }
 
 // Finishes one internal node whose children are both complete: the node's record, and its own box and height for the
@@ -615,22 +619,31 @@ __global__ __launch_bounds__(kClimbThreads) void k_refit_climb(const float4* __r
             float b0[6], b1[6];
             finish_node(TA, TB, TC, node, c.x, c.y, leaves, union_box, nodes, b0, b1);
             finished++;
-            // the node's records for the fine cut (few up here: a counter update each)
-            if (leaves.y - leaves.x + 1u > kFineMax) {
+            // The node's records for the fine cut.  The counter is one address for the whole GPU and its updates take
+            // their turns: the lanes of the wave that are still climbing (the others have left the loop) update it
+            // once between them.
+            {
                 const uint32_t gamma = c.x & 0x7FFFFFFFu;
                 const uint32_t n0 = gamma - leaves.x + 1u, n1 = leaves.y - gamma;
-                if (n0 <= kFineMax) {
-                    const uint32_t at = atomicAdd(fine_count, 1u);
-                    if (at < fine_cap) {
-                        float4* r = (float4*)fine + 2 * (size_t)at;
+                const bool big = leaves.y - leaves.x + 1u > kFineMax;
+                const bool f0 = big && n0 <= kFineMax, f1 = big && n1 <= kFineMax;
+                const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
+                if ((m0 | m1) != 0ull) { // (the same for all of them)
+                    const uint32_t lane = threadIdx.x & 63u;
+                    const int leader = __ffsll((long long)__ballot(true)) - 1;
+                    uint32_t at = 0;
+                    if ((int)lane == leader) at = atomicAdd(fine_count, (uint32_t)(__popcll(m0) + __popcll(m1)));
+                    at = __shfl(at, leader);
+                    const uint64_t below = (1ull << lane) - 1ull;
+                    const uint32_t at0 = at + (uint32_t)__popcll(m0 & below);
+                    const uint32_t at1 = at + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & below);
+                    if (f0 && at0 < fine_cap) {
+                        float4* r = (float4*)fine + 2 * (size_t)at0;
                         r[0] = make_float4(b0[0], b0[1], b0[2], __uint_as_float(leaves.x));
                         r[1] = make_float4(b0[3], b0[4], b0[5], __uint_as_float(n0));
                     }
-                }
-                if (n1 <= kFineMax) {
-                    const uint32_t at = atomicAdd(fine_count, 1u);
-                    if (at < fine_cap) {
-                        float4* r = (float4*)fine + 2 * (size_t)at;
+                    if (f1 && at1 < fine_cap) {
+                        float4* r = (float4*)fine + 2 * (size_t)at1;
                         r[0] = make_float4(b1[0], b1[1], b1[2], __uint_as_float(gamma + 1u));
                         r[1] = make_float4(b1[3], b1[4], b1[5], __uint_as_float(n1));
                     }
