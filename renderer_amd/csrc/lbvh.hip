@@ -435,11 +435,28 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     __shared__ uint32_t s_sweep[kChunk]; // sweep that finished the node, kOpen while it waits
     const uint32_t chunk = blockIdx.x; // (taking the chunks XCD by XCD instead makes no difference)
     const uint32_t t = threadIdx.x, base = chunk * kChunk, i = base + t;
+    // Everything this lane reads by its own index is asked for at once, and what hangs on those answers (the record,
+    // the leaves of children in other chunks) in a second round: a workgroup lives for some thirty microseconds, most
+    // of them waiting, and every round of loads that follows another is one or two of them.
+    const bool valid = i + 1u < n;
+    const uint32_t src = i < n ? order[i] : 0u;
+    uint32_t c0 = 0, c1 = 0, up = 0xFFFFFFFFu;
+    uint2 leaves = make_uint2(0u, 0u);
+    if (valid) {
+        const uint2 c = ((const uint2*)child)[i];
+        c0 = c.x, c1 = c.y;
+        leaves = range[i];
+        up = parent[i]; // (the root has none: 0xFFFFFFFF)
+    }
+    const bool leaf0 = (c0 >> 31) != 0u, leaf1 = (c1 >> 31) != 0u;
+    const uint32_t k0 = (c0 & 0x7FFFFFFFu) - base, k1 = (c1 & 0x7FFFFFFFu) - base; // >= kChunk: in another chunk
+    uint2 far0 = make_uint2(0u, 1u), far1 = make_uint2(0u, 1u); // leaves of a child node of another chunk
+    if (valid && !leaf0 && k0 >= kChunk) far0 = range[c0];
+    if (valid && !leaf1 && k1 >= kChunk) far1 = range[c1];
     if (i < n) {
         // The gather into sorted order happens here, on the way: the triangle at sorted position i is the assembled
         // record order[i].  (A kernel of its own for it read the records, wrote them sorted, and this one read them
         // again: a sixth of a five-million-triangle build.)
-        const uint32_t src = order[i];
         const float4* rec = T0 + 3 * (size_t)src;
         const float4 a = rec[0], b = rec[1], c = rec[2];
         TA[i] = a, TB[i] = b, TC[i] = c;
@@ -449,18 +466,8 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
 #pragma unroll
         for (int a = 0; a < 3; a++) s_leaf[a][t] = lo[a], s_leaf[3 + a][t] = hi[a];
     }
-    const bool valid = i + 1u < n;
-    uint32_t c0 = 0, c1 = 0;
-    if (valid) {
-        const uint2 c = ((const uint2*)child)[i];
-        c0 = c.x, c1 = c.y;
-    }
     s_sweep[t] = kOpen;
-    const bool leaf0 = (c0 >> 31) != 0u, leaf1 = (c1 >> 31) != 0u;
-    const uint32_t k0 = (c0 & 0x7FFFFFFFu) - base, k1 = (c1 & 0x7FFFFFFFu) - base; // >= kChunk: in another chunk
     bool open = valid && k0 < kChunk && k1 < kChunk;
-    uint2 leaves = make_uint2(0u, 0u);
-    if (valid) leaves = range[i];
     float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0}, u[6];
     uint32_t height = kOpen;
     __syncthreads();
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
         nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
         nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
         // the node's own box is read again only by a parent that is not finished here (or, the root's, by the host)
-        const uint32_t p = parent[i] - base; // the root has no parent: 0xFFFFFFFF is in no chunk
+        const uint32_t p = up - base; // the root has no parent: 0xFFFFFFFF is in no chunk
         if (p >= kChunk || s_sweep[p] == kOpen) {
             float4* ub = (float4*)union_box + 2 * (size_t)i;
             ub[0] = make_float4(u[0], u[1], u[2], u[3]);
@@ -502,19 +509,10 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     const bool crossing = valid && height == kOpen;
     uint32_t arrived = 0;
     if (crossing) {
-        const uint32_t cs[2] = {c0, c1};
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint32_t c = cs[k];
-            if (c >> 31) {
-                arrived++; // a leaf: the launches per level read its triangle themselves
-            } else if (c - base < kChunk) {
-                arrived += s_sweep[c - base] != kOpen;
-            } else { // a node of another chunk: finished there if its leaves are all in that chunk
-                const uint2 r = range[c];
-                arrived += r.x / kChunk == r.y / kChunk;
-            }
-        }
+        // a leaf counts (the climb reads its triangle itself); a node of this chunk if it was finished here; a node
+        // of another chunk if its leaves all lie in that chunk: it is finished there
+        arrived += leaf0 ? 1u : k0 < kChunk ? (s_sweep[k0] != kOpen ? 1u : 0u) : (far0.x / kChunk == far0.y / kChunk ? 1u : 0u);
+        arrived += leaf1 ? 1u : k1 < kChunk ? (s_sweep[k1] != kOpen ? 1u : 0u) : (far1.x / kChunk == far1.y / kChunk ? 1u : 0u);
         arrive[i] = arrived;
     }
     const uint32_t finished = (uint32_t)__syncthreads_count(valid && !crossing);
@@ -527,7 +525,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     if (ready) {
         const uint32_t at = boundary_slot(i, leaves, kChunk);
         s_taken[at & 1u] = 1u;
-        slots[2 * (size_t)at] = make_uint4(i + 1u, c0, c1, parent[i]);
+        slots[2 * (size_t)at] = make_uint4(i + 1u, c0, c1, up);
         slots[2 * (size_t)at + 1] = make_uint4(leaves.x, leaves.y, 0u, 0u);
     }
     __syncthreads();
