@@ -65,6 +65,8 @@ struct inv_ctx {
     // what a scene build needs only while it runs; kept for the next build of this context (inv_ctx_trim frees it)
     void* build_scratch = nullptr;
     size_t build_scratch_bytes = 0;
+    int build_sort_hint = 0;      // see build_lbvh: kept from one build to the next of as many triangles (a scene
+    uint32_t build_sort_ntri = 0; // that is built again and again), forgotten when another scene comes
 
     unsigned char* noalloc = nullptr; // this GPU's copy of `scratch` (inv_render_noalloc)
     uint32_t live_scenes = 0;         // scenes built on this context and not yet destroyed
@@ -521,7 +523,8 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         }
         if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0, tree ? 3u : 1u, bounds)) != hipSuccess)
             return bail(e, "assemble kernel");
-        if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds)) != hipSuccess) return bail(e, "LBVH build");
+        if (ctx->build_sort_ntri != d.ntri) ctx->build_sort_hint = 0, ctx->build_sort_ntri = d.ntri;
+        if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds, &ctx->build_sort_hint)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
     ctx->live_scenes++;

@@ -167,6 +167,9 @@ size_t lbvh_keep_bytes(uint32_t ntri);
 size_t lbvh_scratch_bytes(uint32_t ntri);
 // `bounds`: what launch_assemble left for these records, in memory from lbvh_take_bounds (part of the scratch bytes).
 float* lbvh_take_bounds(Arena& scratch, uint32_t n);
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* records, const float* bounds);
+// `sort_hint` (or null): where in the build's list of sorts, shortest first, this build starts and where it ended
+// (0 to begin with; the caller keeps it from build to build).
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* records, const float* bounds,
+                      int* sort_hint);
 
 } // namespace inv

@@ -260,25 +260,25 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
     }
 }
 
-// The short form of the sort: five passes order the keys by their upper 40 bits (stably, so keys that agree there stay
-// in index order); what is left is to order every run of keys with equal upper bits by the lower 24.  Such runs are
-// triangles whose box centres share a cell of 1/8192 of the scene's extent per axis: one or a few, unless triangles
-// repeat.  Every key finds its run by looking at its neighbours and its place in it by counting the keys of the run
-// that go before it (smaller, or equal and earlier).  A run of more than kRunMax keys is copied as it is and the flag
-// is raised: the host then sorts again with all eight passes.  (A key looks at most kRunMax places either way, so
-// all keys of a run come to the same verdict: a shorter run is seen whole by each of them, a longer one is seen
-// whole and counted, or not seen whole.)
-constexpr int kShortSortShift = 24;
+// The short forms of the sort: the passes over the upper digits only order the keys by their bits from `shift` up
+// (stably, so keys that agree there stay in index order); what is left is to order every run of keys with equal upper
+// bits by the lower ones.  Such runs are triangles whose box centres share a cell of the scene's extent -- from bit 32
+// up a cell is a 2048th of it in x and a 1024th in y and z, from bit 24 up an 8192nd per axis -- one or a few, unless
+// the scene is very large or triangles repeat.  Every key finds its run by looking at its neighbours and its place in
+// it by counting the keys of the run that go before it (smaller, or equal and earlier).  A run of more than kRunMax
+// keys is copied as it is and the flag is raised: the host then sorts again with more passes.  (A key looks at most
+// kRunMax places either way, so all keys of a run come to the same verdict: a shorter run is seen whole by each of
+// them, a longer one is seen whole and counted, or not seen whole.)
 constexpr uint32_t kRunMax = 48;
 __global__ __launch_bounds__(256) void k_sort_runs(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t n,
-                                                   uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                   int shift, uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                    uint32_t* __restrict__ too_long) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const uint64_t k = kin[i], hi = k >> kShortSortShift;
+    const uint64_t k = kin[i], hi = k >> shift;
     uint32_t a = i, b = i + 1u;
-    while (a > 0u && i - a < kRunMax && (kin[a - 1u] >> kShortSortShift) == hi) a--;
-    while (b < n && b - i <= kRunMax && (kin[b] >> kShortSortShift) == hi) b++; // (b - i counts key i itself)
+    while (a > 0u && i - a < kRunMax && (kin[a - 1u] >> shift) == hi) a--;
+    while (b < n && b - i <= kRunMax && (kin[b] >> shift) == hi) b++; // (b - i counts key i itself)
     uint32_t at = i;
     if (b - a > kRunMax) {
         *too_long = 1u; // (every thread that comes here writes the same value)
@@ -847,22 +847,30 @@ size_t lbvh_scratch_bytes(uint32_t n) {
 }
 
 static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
-                                  const float* bounds, bool short_sort);
+                                  const float* bounds, int sort_shift);
 
 float* lbvh_take_bounds(Arena& tmp, uint32_t n) { return n < 2 ? nullptr : tmp.take<float>((size_t)bounds_blocks_for(n) * 24); }
 
-hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, const float* bounds) {
+hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, const float* bounds,
+                      int* sort_hint) {
+    // Four passes and the runs, five passes and the runs, or all eight: the first that meets no run it cannot order
+    // (a build that gives up has cost as much as one that does not, so the caller's next build starts where this one
+    // ended).
+    static const int shifts[] = {32, 24, 0};
+    int at = sort_hint ? *sort_hint : 0;
+    at = at < 0 ? 0 : at > 2 ? 2 : at;
     const size_t keep_used = keep.used, tmp_used = tmp.used;
-    hipError_t e = build_lbvh_with(s, sc, keep, tmp, records, bounds, true);
-    if (e == hipErrorNotReady) { // long runs of keys that agree in their upper bits (repeated triangles): all eight passes
+    hipError_t e = hipErrorNotReady;
+    for (; at < 3 && e == hipErrorNotReady; at++) {
         keep.used = keep_used, tmp.used = tmp_used;
-        e = build_lbvh_with(s, sc, keep, tmp, records, bounds, false);
+        e = build_lbvh_with(s, sc, keep, tmp, records, bounds, shifts[at]);
     }
+    if (sort_hint && e == hipSuccess) *sort_hint = at - 1;
     return e;
 }
 
 static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
-                                  const float* bounds, bool short_sort) {
+                                  const float* bounds, int sort_shift) {
     const uint32_t n = sc.ntri;
     sc.has_bvh = false;
     if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
@@ -903,15 +911,16 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     HIP_RET(hipMemsetAsync(words, 0, build_words_for(n) * 4, s));
     uint32_t* const too_long = words + kWUnsorted;
     hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(1024), 0, s, bounds, bounds_blocks, d_bbox);
-    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, n, d_bbox, sc.morton, sc.order);
-    // 63 significant key bits -> 8 passes; an even number of passes leaves the result in sc.morton / sc.order.  The
-    // short form: the upper five digits only (an odd number: the result is in the other pair of arrays), then
-    // k_sort_runs, which writes sc.morton / sc.order.
-    uint64_t* kin = sc.morton;
-    uint32_t* vin = sc.order;
-    uint64_t* kout = keys_alt;
-    uint32_t* vout = vals_alt;
-    for (int pass = short_sort ? kShortSortShift / 8 : 0; pass < 8; pass++) {
+    // 63 significant key bits -> 8 passes of 8 bits, or the upper digits only and k_sort_runs for the rest.  The
+    // passes and the run kernel go from one pair of arrays to the other; the keys start in the pair that makes them
+    // end in sc.morton / sc.order.
+    const int steps = (8 - sort_shift / 8) + (sort_shift ? 1 : 0);
+    uint64_t* kin = (steps & 1) ? keys_alt : sc.morton;
+    uint32_t* vin = (steps & 1) ? vals_alt : sc.order;
+    uint64_t* kout = (steps & 1) ? sc.morton : keys_alt;
+    uint32_t* vout = (steps & 1) ? sc.order : vals_alt;
+    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, n, d_bbox, kin, vin);
+    for (int pass = sort_shift / 8; pass < 8; pass++) {
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_sort_hist, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
         const uint32_t ncount = ntiles * 256u;
@@ -927,7 +936,9 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
-    if (short_sort) hipLaunchKernelGGL(k_sort_runs, grid_n, blk, 0, s, (const uint64_t*)kin, (const uint32_t*)vin, n, kout, vout, too_long);
+    if (sort_shift)
+        hipLaunchKernelGGL(k_sort_runs, grid_n, blk, 0, s, (const uint64_t*)kin, (const uint32_t*)vin, n, sort_shift, kout, vout,
+                           too_long);
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     uint32_t* fine_count = words + kWFineCount;
@@ -953,7 +964,7 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     const uint32_t* summary = host_words + kWSummary;
     HIP_RET(hipMemcpyAsync(host_words, words, sizeof host_words, hipMemcpyDeviceToHost, s));
     HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
-    if (short_sort && host_words[kWUnsorted] != 0u) return hipErrorNotReady; // the caller sorts again with all eight passes
+    if (sort_shift && host_words[kWUnsorted] != 0u) return hipErrorNotReady; // the caller sorts again with more passes
     const uint64_t finished = (uint64_t)host_words[kWFinishedChunks] + host_words[kWFinishedClimb];
     if (finished != n - 1 || host_words[kWRootDone] == 0u || summary[0] == kCutUnfinished) return hipErrorUnknown; // every internal node must have been refitted
     sc.ncut = summary[0];

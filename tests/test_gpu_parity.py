@@ -616,9 +616,11 @@ def test_lbvh_structure_random(oracle, gpu_ctx, ntri, seed):
 @pytest.mark.parametrize("where", ["first", "middle", "last"])
 def test_lbvh_runs_of_equal_keys(oracle, gpu_ctx, copies, where):
     """One triangle many times over (equal keys, ordered by index), at the low end, in the middle and at the high end
-    of the sorted order: the build's short sort orders runs of up to 48 keys that share their upper bits in place
-    and sorts again in full for longer ones; both sides of that limit, and runs that touch the ends of the array."""
-    ntri = 3000
+    of the sorted order: the build's short sorts order runs of up to 48 keys that share their upper bits in place
+    and the build sorts again with more passes for longer ones; both sides of that limit, and runs that touch the ends
+    of the array.  (A context remembers which sort a scene of so many triangles needed: every case has its own
+    triangle count, so every case starts with the shortest.)"""
+    ntri = 3000 + copies + {"first": 0, "middle": 1000, "last": 2000}[where]
     xyz, faces = objfmt.random_soup(ntri, seed=77, size=0.004)
     xyzw = np.zeros((len(xyz), 4), np.float32)
     xyzw[:, :3] = xyz
