@@ -91,10 +91,11 @@ int inv_ctx_synchronize(inv_ctx* ctx);
 /* The hipStream_t the context enqueues on (the one given to inv_ctx_create, or the one it created): callers that
  * follow a draw with work of their own (a collective, a copy) enqueue it there or order their stream after it. */
 int inv_ctx_stream(inv_ctx* ctx, void** hip_stream);
-/* A context keeps the device memory its last scene build needed only while it ran (about 120 bytes per triangle),
- * so that the next build does not allocate it again: the counterpart of the staging buffer transferData creates and
+/* A context keeps the device memory its last scene build needed only while it ran (about 120 bytes per triangle)
+ * and the allocation of the largest scene destroyed since (for the next build that fits it),
+ * so that the next build does not allocate them again: the counterpart of the staging buffer transferData creates and
  * destroys on every call, with the TODO to keep it (src/invert.cpp:991-992, 1000-1032, 1078-1079).  This call
- * releases it; inv_ctx_destroy does too. */
+ * releases both; inv_ctx_destroy does too. */
 int inv_ctx_trim(inv_ctx* ctx);
 
 /* ---- mesh: struct Obj ------------------------------------------------------------------------------------ */

@@ -65,6 +65,10 @@ struct inv_ctx {
     // what a scene build needs only while it runs; kept for the next build of this context (inv_ctx_trim frees it)
     void* build_scratch = nullptr;
     size_t build_scratch_bytes = 0;
+    // The allocation of the last scene destroyed, for the next build that fits it (a scene that is built again and
+    // again, each build after the old scene is gone: allocating 0.8 GB takes 40 us, a twentieth of the build).
+    void* spare_arena = nullptr;
+    size_t spare_arena_bytes = 0;
     int build_sort_hint = 0;      // see build_lbvh: kept from one build to the next of as many triangles (a scene
     uint32_t build_sort_ntri = 0; // that is built again and again), forgotten when another scene comes
 
@@ -257,6 +261,7 @@ int inv_ctx_destroy(inv_ctx* ctx) {
         if (ctx->flight_done[i]) (void)hipEventDestroy(ctx->flight_done[i]);
     }
     if (ctx->build_scratch) (void)hipFree(ctx->build_scratch);
+    if (ctx->spare_arena) (void)hipFree(ctx->spare_arena);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return INV_OK;
@@ -282,6 +287,8 @@ int inv_ctx_trim(inv_ctx* ctx) {
         HIP_TRY(hipFree(ctx->build_scratch));
     }
     ctx->build_scratch = nullptr, ctx->build_scratch_bytes = 0;
+    if (ctx->spare_arena) HIP_TRY(hipFree(ctx->spare_arena));
+    ctx->spare_arena = nullptr, ctx->spare_arena_bytes = 0;
     return INV_OK;
 }
 
@@ -452,7 +459,13 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         delete s;
         return rc;
     };
-    if ((e = hipMalloc((void**)&keep.base, keep.size)) != hipSuccess) return bail(e, "hipMalloc(scene)");
+    if (ctx->spare_arena && ctx->spare_arena_bytes >= keep.size && ctx->spare_arena_bytes <= keep.size + keep.size / 2) {
+        keep.base = (char*)ctx->spare_arena, d.arena_bytes = ctx->spare_arena_bytes; // (its last reader is long done)
+        ctx->spare_arena = nullptr, ctx->spare_arena_bytes = 0;
+    } else {
+        if ((e = hipMalloc((void**)&keep.base, keep.size)) != hipSuccess) return bail(e, "hipMalloc(scene)");
+        d.arena_bytes = keep.size;
+    }
     d.arena = keep.base;
     if (ctx->build_scratch_bytes < scratch.size) {
         if (ctx->build_scratch) (void)hipFree(ctx->build_scratch); // no build is running: every build ends with a sync
@@ -524,7 +537,10 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0, tree ? 3u : 1u, bounds)) != hipSuccess)
             return bail(e, "assemble kernel");
         if (ctx->build_sort_ntri != d.ntri) ctx->build_sort_hint = 0, ctx->build_sort_ntri = d.ntri;
-        if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds, &ctx->build_sort_hint)) != hipSuccess) return bail(e, "LBVH build");
+        // (a mesh of up to 2 MB stays in every XCD's 4 MB L2 while the kernels that read it run)
+        const bool cached_mesh = (size_t)nv * 16 + (size_t)base_ntri * 12 <= (size_t)2 << 20;
+        const MeshSource mesh_src = {cached_mesh ? (const float4*)d.xyzw : nullptr, d.idx, d_tr, base_ntri, ninst};
+        if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds, mesh_src, &ctx->build_sort_hint)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");
     ctx->live_scenes++;
@@ -553,6 +569,15 @@ int inv_scene_destroy(inv_scene* scene) {
     (void)hipStreamSynchronize(scene->ctx->stream);
     for (hipStream_t fs : scene->ctx->flight)
         if (fs) (void)hipStreamSynchronize(fs); // draws in flight still read the scene
+    {   // the scene's allocation becomes the context's spare one if it is the larger of the two
+        inv_ctx* ctx = scene->ctx;
+        DeviceScene& d = scene->d;
+        if (d.arena && d.arena_bytes > ctx->spare_arena_bytes) {
+            if (ctx->spare_arena) (void)hipFree(ctx->spare_arena);
+            ctx->spare_arena = d.arena, ctx->spare_arena_bytes = d.arena_bytes;
+            d.arena = nullptr;
+        }
+    }
     free_device_scene(scene->d);
     free_frame_scratch(scene->main);
     for (auto& fsr : scene->flight) free_frame_scratch(fsr);

@@ -107,6 +107,7 @@ struct DeviceScene {
     float* fine = nullptr;         // the fine cut: every subtree of at most kFineMax leaves under a larger parent,
                                    // 8 floats per record (lo xyz, first leaf, hi xyz, leaf count), in no particular order
     uint32_t nfine = 0;            // records of the fine cut; 0: the scene has none (a few triangles, or too unbalanced)
+    size_t arena_bytes = 0;        // size of the one allocation that holds every array above
     bool has_bvh = false;
     uint32_t height = 0;           // height of the root (a node over two leaves has height 1)
     float bbox[6] = {0, 0, 0, 0, 0, 0};
@@ -114,6 +115,13 @@ struct DeviceScene {
 
 hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, const inv_camera& cam, float* clip4,
                                 float* color3);
+// What primitive assembly reads: the Obj arrays in device memory and the instances' translations.
+struct MeshSource {
+    const float4* xyzw;
+    const uint32_t* idx;
+    const float* translations; // xyz per instance, or null
+    uint32_t base_ntri, ninst;
+};
 // Triangle g's three 16-byte items go to A[g * stride], B[g * stride], C[g * stride] (in float4 units): stride 1
 // fills three arrays, stride 3 with B = A + 4 floats and C = A + 8 floats one array of 48-byte records.
 // `bounds` (or null): bounds_blocks_for(triangles) entries of six floats, the box of a share of the triangles each
@@ -169,7 +177,9 @@ size_t lbvh_scratch_bytes(uint32_t ntri);
 float* lbvh_take_bounds(Arena& scratch, uint32_t n);
 // `sort_hint` (or null): where in the build's list of sorts, shortest first, this build starts and where it ended
 // (0 to begin with; the caller keeps it from build to build).
+// `mesh`: what the records were assembled from, when that is small enough to stay in every L2 (the Morton keys
+// are then made from it instead of from the records: a pass less over the triangles), or a MeshSource without arrays.
 hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* records, const float* bounds,
-                      int* sort_hint);
+                      const MeshSource& mesh, int* sort_hint);
 
 } // namespace inv

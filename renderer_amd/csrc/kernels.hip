@@ -55,28 +55,14 @@ hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, c
 // With `bounds`, every workgroup also leaves the box of its triangles there (lo xyz, hi xyz: the first stage of the
 // scene bounds the tree build starts from), taken from the records as stored -- a corner is A + B, not the vertex
 // it was made from -- so that the build does not have to read them all again for it.
-__global__ __launch_bounds__(256) void k_assemble(const float4* __restrict__ xyzw, const uint32_t* __restrict__ idx,
-                                                  uint32_t base_ntri, const float* __restrict__ translations,
-                                                  uint32_t ninst, float4* __restrict__ A, float4* __restrict__ B,
+__global__ __launch_bounds__(256) void k_assemble(MeshSource m, float4* __restrict__ A, float4* __restrict__ B,
                                                   float4* __restrict__ C, uint32_t stride, float* __restrict__ bounds) {
-    const uint64_t total = (uint64_t)base_ntri * ninst;
+    const uint64_t total = (uint64_t)m.base_ntri * m.ninst;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t inst = (uint32_t)(g / base_ntri), k = (uint32_t)(g % base_ntri);
-        float4 a = xyzw[idx[3 * (size_t)k + 0]];
-        float4 b = xyzw[idx[3 * (size_t)k + 1]];
-        float4 c = xyzw[idx[3 * (size_t)k + 2]];
-        if (translations) {
-            float tx = translations[3 * (size_t)inst + 0], ty = translations[3 * (size_t)inst + 1],
-                  tz = translations[3 * (size_t)inst + 2];
-            a.x = a.x + tx, a.y = a.y + ty, a.z = a.z + tz;
-            b.x = b.x + tx, b.y = b.y + ty, b.z = b.z + tz;
-            c.x = c.x + tx, c.y = c.y + ty, c.z = c.z + tz;
-        }
+        float4 ra, rb, rc;
+        assemble_record(m, g, ra, rb, rc);
         const uint64_t at = g * stride;
-        const float4 ra = make_float4(a.x, a.y, a.z, __uint_as_float((uint32_t)g));
-        const float4 rb = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.z);
-        const float4 rc = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, c.z);
         A[at] = ra, B[at] = rb, C[at] = rc;
         if (bounds) {
             float l[3], h[3];
@@ -96,8 +82,8 @@ hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const 
     if (total == 0) return hipSuccess;
     // (with bounds: as many workgroups as the bounds have first-stage entries; without, one triangle per lane)
     const unsigned blocks = bounds ? bounds_blocks_for((uint32_t)total) : (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, (const float4*)xyzw, idx, base_ntri, translations, ninst,
-                       (float4*)A, (float4*)B, (float4*)C, stride, bounds);
+    const MeshSource m = {(const float4*)xyzw, idx, translations, base_ntri, ninst};
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, m, (float4*)A, (float4*)B, (float4*)C, stride, bounds);
     return hipGetLastError();
 }
 

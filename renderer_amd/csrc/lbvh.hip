@@ -63,13 +63,21 @@ __device__ __forceinline__ uint32_t grid21(float c, float lo, float ext) {
     return (uint32_t)s;
 }
 
-__global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, uint32_t n,
+// The record comes from memory, or -- with `mesh` -- is assembled again from a mesh that the caches hold (the same
+// floats: assemble_record), which saves reading 48 bytes per triangle.
+__global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, MeshSource mesh, uint32_t n,
                                                 const float* __restrict__ bbox, uint64_t* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    float4 ra, rb, rc;
+    if (mesh.xyzw) { // (the same for every lane)
+        assemble_record(mesh, i, ra, rb, rc);
+    } else {
+        ra = T[3 * (size_t)i], rb = T[3 * (size_t)i + 1], rc = T[3 * (size_t)i + 2];
+    }
     float lo[3], hi[3];
-    tri_box(T[3 * (size_t)i], T[3 * (size_t)i + 1], T[3 * (size_t)i + 2], lo, hi);
+    tri_box(ra, rb, rc, lo, hi);
     float ex = bbox[3] - bbox[0], ey = bbox[4] - bbox[1], ez = bbox[5] - bbox[2];
     float cx = (lo[0] + hi[0]) * 0.5f, cy = (lo[1] + hi[1]) * 0.5f, cz = (lo[2] + hi[2]) * 0.5f;
     keys[i] = (expand21(grid21(cx, bbox[0], ex)) << 2) | (expand21(grid21(cy, bbox[1], ey)) << 1) |
@@ -159,12 +167,14 @@ __global__ __launch_bounds__(1024) void k_scan_local(uint32_t* __restrict__ coun
 // and the last two need no exchange between waves: per round eight ballots find the lanes with the same digit and
 // the wave's own counters in LDS carry the rounds.  One barrier, then thread d turns the four waves' counts of digit
 // d into their prefix.  `totals`: the offsets' second scan level (offset of each block of kScanBlock counters), or
-// null when the offsets are already complete.
+// null when the offsets are already complete; with `raw_blocks` they are that many block totals not yet added up
+// (at most kSortThreads of them), and every workgroup adds up the ones before its counters itself (a scan over the
+// workgroup's lanes, on the side), against a launch of one workgroup between the passes' other kernels.
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* __restrict__ keys_in,
                                                                const uint32_t* __restrict__ vals_in, uint32_t n,
                                                                int shift, uint32_t ntiles,
                                                                const uint32_t* __restrict__ offsets,
-                                                               const uint32_t* __restrict__ totals,
+                                                               const uint32_t* __restrict__ totals, uint32_t raw_blocks,
                                                                uint64_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out) {
     __shared__ uint64_t s_key[kSortTile];
@@ -179,10 +189,13 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
     if (tile >= ntiles) return; // block-uniform
     const uint32_t base = tile * kSortTile;
     const uint32_t tile_n = min((uint32_t)kSortTile, n - base);
-    {
-        const uint32_t at = tid * ntiles + tile;
-        s_goff[tid] = offsets[at] + (totals ? totals[at / kScanBlock] : 0u);
-    }
+    __shared__ uint32_t s_tot[kSortThreads], s_wtot[4];
+    const uint32_t at = tid * ntiles + tile; // this thread's digit, this tile
+    uint32_t goff = offsets[at], block_total = 0;
+    if (raw_blocks)
+        block_total = tid < raw_blocks ? totals[tid] : 0u;
+    else if (totals)
+        goff += totals[at / kScanBlock];
 #pragma unroll
     for (int w = 0; w < 4; w++) s_wave[w][tid] = 0;
     __syncthreads();
@@ -216,8 +229,23 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
         const uint32_t c0 = s_wave[0][tid], c1 = s_wave[1][tid], c2 = s_wave[2][tid], c3 = s_wave[3][tid];
         s_wave[0][tid] = 0, s_wave[1][tid] = c0, s_wave[2][tid] = c0 + c1, s_wave[3][tid] = c0 + c1 + c2;
         s_run[tid] = c0 + c1 + c2 + c3;
+        // on the side: the block totals before each block, within the wave here, the waves before it added below
+        uint32_t incl = block_total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= (unsigned)o) incl += v;
+        }
+        s_tot[tid] = incl - block_total;
+        if (lane == 63) s_wtot[wave] = incl;
     }
     __syncthreads();
+    if (raw_blocks) {
+        const uint32_t blk = at / kScanBlock;
+        goff += s_tot[blk];
+        for (uint32_t w = 0; w < (blk >> 6); w++) goff += s_wtot[w];
+    }
+    s_goff[tid] = goff; // (read after the barriers below)
     // exclusive scan of the tile's digit counts -> tile-local digit start (s_run becomes the start)
     {
         uint32_t c = s_run[tid];
@@ -847,12 +875,12 @@ size_t lbvh_scratch_bytes(uint32_t n) {
 }
 
 static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
-                                  const float* bounds, int sort_shift);
+                                  const float* bounds, const MeshSource& mesh, int sort_shift);
 
 float* lbvh_take_bounds(Arena& tmp, uint32_t n) { return n < 2 ? nullptr : tmp.take<float>((size_t)bounds_blocks_for(n) * 24); }
 
 hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records, const float* bounds,
-                      int* sort_hint) {
+                      const MeshSource& mesh, int* sort_hint) {
     // Four passes and the runs, five passes and the runs, or all eight: the first that meets no run it cannot order
     // (a build that gives up has cost as much as one that does not, so the caller's next build starts where this one
     // ended).
@@ -863,14 +891,14 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     hipError_t e = hipErrorNotReady;
     for (; at < 3 && e == hipErrorNotReady; at++) {
         keep.used = keep_used, tmp.used = tmp_used;
-        e = build_lbvh_with(s, sc, keep, tmp, records, bounds, shifts[at]);
+        e = build_lbvh_with(s, sc, keep, tmp, records, bounds, mesh, shifts[at]);
     }
     if (sort_hint && e == hipSuccess) *sort_hint = at - 1;
     return e;
 }
 
 static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
-                                  const float* bounds, int sort_shift) {
+                                  const float* bounds, const MeshSource& mesh, int sort_shift) {
     const uint32_t n = sc.ntri;
     sc.has_bvh = false;
     if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
@@ -919,20 +947,25 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     uint32_t* vin = (steps & 1) ? vals_alt : sc.order;
     uint64_t* kout = (steps & 1) ? sc.morton : keys_alt;
     uint32_t* vout = (steps & 1) ? sc.order : vals_alt;
-    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, n, d_bbox, kin, vin);
+    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, mesh, n, d_bbox, kin, vin);
     for (int pass = sort_shift / 8; pass < 8; pass++) {
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_sort_hist, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
         const uint32_t ncount = ntiles * 256u;
+        uint32_t raw_blocks = 0;
         if (ncount <= 16384u) {
             hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, counts, ncount);
         } else {
             const uint32_t nb = (ncount + kScanBlock - 1) / kScanBlock;
             hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(1024), 0, s, counts, ncount, scan_totals);
-            hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, scan_totals, nb);
+            static const bool scan_kernel = getenv("INV_SORT_SCAN_KERNEL") && atoi(getenv("INV_SORT_SCAN_KERNEL"));
+            if (nb <= (uint32_t)kSortThreads && !scan_kernel)
+                raw_blocks = nb; // the scatter adds them up itself
+            else
+                hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, scan_totals, nb);
         }
         hipLaunchKernelGGL(k_sort_scatter, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, vin, n, shift, ntiles, counts,
-                           (const uint32_t*)(ncount <= 16384u ? nullptr : scan_totals), kout, vout);
+                           (const uint32_t*)(ncount <= 16384u ? nullptr : scan_totals), raw_blocks, kout, vout);
         std::swap(kin, kout);
         std::swap(vin, vout);
     }

@@ -187,6 +187,26 @@ __device__ __forceinline__ void mt_test(const FrameK& f, const Ray& r, const flo
     best.slot = slot;
 }
 
+// Primitive assembly of triangle g: instance g / base_ntri of template triangle g % base_ntri, as the three 16-byte
+// items of its record (A with the primitive id, B = v1 - A, C = v2 - A, each with the vertex's own z in w).  Every
+// kernel that wants the record without reading it back gets the same floats from here.
+__device__ __forceinline__ void assemble_record(const MeshSource& m, uint64_t g, float4& ra, float4& rb, float4& rc) {
+    const uint32_t inst = (uint32_t)(g / m.base_ntri), k = (uint32_t)(g % m.base_ntri);
+    float4 a = m.xyzw[m.idx[3 * (size_t)k + 0]];
+    float4 b = m.xyzw[m.idx[3 * (size_t)k + 1]];
+    float4 c = m.xyzw[m.idx[3 * (size_t)k + 2]];
+    if (m.translations) {
+        const float tx = m.translations[3 * (size_t)inst + 0], ty = m.translations[3 * (size_t)inst + 1],
+                    tz = m.translations[3 * (size_t)inst + 2];
+        a.x = a.x + tx, a.y = a.y + ty, a.z = a.z + tz;
+        b.x = b.x + tx, b.y = b.y + ty, b.z = b.z + tz;
+        c.x = c.x + tx, c.y = c.y + ty, c.z = c.z + tz;
+    }
+    ra = make_float4(a.x, a.y, a.z, __uint_as_float((uint32_t)g));
+    rb = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.z);
+    rc = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, c.z);
+}
+
 // Box of a triangle record as stored (A, B = v1 - A, C = v2 - A): the corners are A, A + B, A + C, not the vertices
 // they were made from.
 __device__ __forceinline__ void tri_box(const float4& A, const float4& B, const float4& C, float lo[3], float hi[3]) {

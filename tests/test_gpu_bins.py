@@ -82,11 +82,13 @@ def test_fine_cut_of_the_large_instanced_scene(gpu_ctx, bunny_mesh):
     scene.close()
 
 
-def _parity_suite_with(**env_vars):
+_PARITY_NAMES = ("config1 or config2 or shading or jittered or samples_in or odd_extents or moved_camera or soup or tiny "
+                 "or sharding or sparse_composite or turntable or in_flight or batched_draws or overflow or "
+                 "camera_inside or ambient or instanced or ray_along or 8k")
+
+
+def _parity_suite_with(names=_PARITY_NAMES, **env_vars):
     env = dict(os.environ, **env_vars)
-    names = ("config1 or config2 or shading or jittered or samples_in or odd_extents or moved_camera or soup or tiny or "
-             "sharding or sparse_composite or turntable or in_flight or batched_draws or overflow or camera_inside or "
-             "ambient or instanced or ray_along or 8k")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
                         os.path.join(ROOT, "tests", "test_gpu_configs.py"), "-x", "-q", "-m", "gpu", "-k", names,
                         "--timeout", "300", "--timeout-method", "thread", "-p", "no:cacheprovider"],
@@ -106,6 +108,13 @@ def test_parity_suite_with_one_lane_per_triangle():
     drawn one lane per triangle into a visibility buffer (by default only frames whose triangles are far smaller than
     a pixel are), including shards of several ranks and frames with occlusion rays."""
     _parity_suite_with(INV_SCATTER="1")
+
+
+def test_lbvh_suite_with_the_scan_kernel_between_the_sort_kernels():
+    """The LBVH structure tests again with INV_SORT_SCAN_KERNEL=1: the second level of the radix sort's scan runs as a
+    kernel of its own, as it does for scenes of more than eight million triangles (smaller ones leave it to the scatter
+    kernel), here on the scenes of 0.7 and 5 million."""
+    _parity_suite_with(names="lbvh_structure_large or config4 or lbvh_runs", INV_SORT_SCAN_KERNEL="1")
 
 
 def test_parity_suite_from_the_coarse_cut():
