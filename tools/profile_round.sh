@@ -27,7 +27,7 @@ timeout -k 10 120 python3 tools/tile_stats.py --blocks > "$O/block_stats.txt" 2>
 timeout -k 10 120 python3 tools/phase_timing.py --flags 67 > "$O/phase_timing_blocks.txt" 2>&1
 bash tools/pmc_phases.sh > /dev/null 2>&1 && cp gpurun_out/pmc_phases.txt "$O/pmc_phases.txt"
 timeout -k 10 300 python3 tools/config4.py > "$O/config4.txt" 2>&1
-(cd /tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d "$O/build_trace" -- python3 $R/tools/config4.py --builds 3 > /dev/null 2>&1)
+(cd /tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d "$O/build_trace" -- python3 $R/tools/config4.py --builds 8 > /dev/null 2>&1)
 python3 tools/build_timeline.py "$O"/build_trace/*/*_kernel_trace.csv > "$O/build_timeline.txt" 2>&1
 bash tools/pmc_cache.sh > /dev/null 2>&1 && cp gpurun_out/pmc_cache.txt "$O/pmc_cache.txt"
 bash tools/pmc_ao.sh > /dev/null 2>&1 && cp gpurun_out/pmc_ao.txt "$O/pmc_ao.txt"
