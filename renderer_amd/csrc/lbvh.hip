@@ -1,6 +1,8 @@
 // GPU LBVH build for gfx950: scene bounds -> 63-bit Morton codes of the triangle box centres ->
-// LDS-staged 8-bit radix sort (stable, so ties keep primitive order) -> Karras hierarchy ->
-// bottom-up refit with one arrival counter per internal node.
+// LDS-staged 8-bit radix sort (stable, so ties keep primitive order; the lower digits by a kernel that
+// orders short runs in place when it can) -> Karras hierarchy -> bottom-up refit: chunks of leaves in
+// LDS (which also gather the triangles into sorted order), then workgroups that climb from the nodes
+// across chunk boundaries to the root, one arrival counter per internal node.
 //
 // The build is deterministic: every float that ends up in a node is a min/max of input floats,
 // the sort is stable and the hierarchy depends only on the sorted keys, so the tree is identical
@@ -20,7 +22,7 @@ constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems; // keys per workgroup per pass
 
 // ------------------------------------------------------------------------------------------
-// 1. triangle boxes + scene bounds (two-stage min/max reduction, no float atomics)
+// 1. scene bounds (two-stage min/max reduction, no float atomics; the first stage is the assembly kernel's)
 // ------------------------------------------------------------------------------------------
 // Workgroups go to the eight XCDs in turn, each with an L2 of its own.  Where neighbouring blocks of work touch
 // neighbouring memory, XCD x takes the x-th eighth of the blocks instead of every eighth block: launch
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void k_sort_runs(const uint64_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// 5. hierarchy: T. Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and
+// 4. hierarchy: T. Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and
 //    k-d Trees", HPG 2012, section 4.  Keys are made unique by appending the sorted position.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int delta(const uint64_t* __restrict__ m, uint32_t n, int64_t i, int64_t j) {
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ m, 
 }
 
 // ------------------------------------------------------------------------------------------
-// 6. refit: the chunks of leaves first, each in LDS, then the nodes that cross chunk boundaries.
+// 5. refit: the chunks of leaves first, each in LDS, then the nodes that cross chunk boundaries.
 //    Node i (16 floats): child0 lo xyz, hi xyz, child1 lo xyz, hi xyz, child0, child1, first and
 //    last sorted leaf under the node (from the hierarchy kernel's range array).  union_box[i] (8 floats)
 //    carries the node's own box and height upwards.
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(kClimbThreads) void k_refit_climb(const float4* __r
 
 
 // ------------------------------------------------------------------------------------------
-// 7. cut: a flat start set for the tile kernel.  The tree is opened breadth-first from the root,
+// 6. cut: a flat start set for the tile kernel.  The tree is opened breadth-first from the root,
 //    level by level, until every open subtree has at most kRangeMax leaves or kCutCap records are in
 //    use.  A record is 8 floats: (lo.xyz, ref) (hi.xyz, count).  count <= kRangeMax: ref is the first
 //    sorted leaf of a range taken whole; otherwise ref is an internal node that still has to be
