@@ -1,6 +1,6 @@
 """Random scenes through the GPU LBVH build against the oracle's sequential restatement: sorted keys, order, hierarchy,
 parents and every box, bit for bit.  Sizes around the sort tile (2048 keys) and the refit chunk (512 leaves) come up
-often; some scenes hold exact duplicates (equal Morton keys: the index tie-break), one triangle up to 200 times (runs
+often, sizes of several spans of 256 chunks now and then; some scenes hold exact duplicates (equal Morton keys: the index tie-break), one triangle up to 200 times (runs
 of equal keys on both sides of the short sort's limit) or are flat (one axis without extent).
 
     python tools/fuzz_lbvh.py [--scenes 300] [--seed 1] [--max-triangles 60000]
@@ -35,6 +35,8 @@ def main():
             n = max(2, int(rng.choice([512, 1024, 2048, 4096, 8192])) * int(rng.integers(1, 6)) + int(rng.integers(-2, 3)))
         elif pick < 0.5:
             n = int(rng.integers(2, 600))
+        elif pick < 0.56:  # more than one span of 256 refit chunks: the climb above the chunks takes two launches
+            n = int(rng.integers(131073, 700000))
         else:
             n = int(rng.integers(2, a.max_triangles))
         xyz, faces = objfmt.random_soup(n, seed=int(rng.integers(0, 1 << 30)), size=float(rng.choice([0.001, 0.01, 0.05])))
