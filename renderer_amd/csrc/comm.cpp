@@ -51,7 +51,8 @@ Rccl* rccl() {
             if (x->handle) break;
         }
         if (!x->handle) {
-            x->error = std::string("cannot open librccl.so.1: ") + (dlerror() ? dlerror() : "?");
+            const char* why = dlerror(); // (a second call would return null: the first one clears the message)
+            x->error = std::string("cannot open librccl.so.1: ") + (why ? why : "?");
             return x;
         }
 #define INV_SYM(field, sym)                                                                  \
