@@ -7,7 +7,7 @@ again, so `value` and `roofline` are HBM figures.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-One step = one batch of --frames-per-step (default 64) frames of the workload rendered through the C ABI
+One step = one batch of --frames-per-step (default 256 for the headline, 64 for the heavier workloads) frames of the workload rendered through the C ABI
 (include/invert.h) with every input (triangles, LBVH) and output buffer resident in HBM; a frame of the headline
 workload lasts a few microseconds, so a single frame per step would leave a handful of steps too short to time.  On one GPU the frames are submitted --frames-per-launch at a time
 (inv_render_batch, default 4: one launch of the tile kernel draws them all) and the submissions go round-robin to
@@ -146,9 +146,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=60)
-    ap.add_argument("--frames-per-step", type=int, default=64,
+    ap.add_argument("--frames-per-step", type=int, default=None,
                     help="a step is one batch of this many frames of the workload (a single frame lasts a few "
-                         "microseconds: too little to time a handful of steps)")
+                         "microseconds: too little to time a handful of steps); default 256 for the workloads whose "
+                         "frames share launches, 64 for the heavier ones")
     ap.add_argument("--workload", default="bunny_1080p_primary_lambert_invert", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=range(1, R.api.MAX_FRAMES_IN_FLIGHT + 1),
                     help="one GPU: frame slots the submissions are dealt to (default: 3 where frames share launches, "
@@ -203,8 +204,14 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    nframes, nwarm = args.steps * args.frames_per_step, args.warmup * args.frames_per_step  # frames timed / warmed up
     wl = WORKLOADS[args.workload]
+    if args.frames_per_step is None:
+        # Frames of a few microseconds: 256 per step, so that 20 steps last some 20 ms and the ramp at the start of the
+        # timed region and the drain at its end (the slots' last launches do not overlap) weigh under 1 %; with 64 a
+        # run of 20 steps read 3.76 us per frame where a long one reads 3.67.  Frames of tens of microseconds and more: 64.
+        light = wl["spp"] < 4 and not wl.get("ao_rays", 0) and wl.get("instances_side", 1) == 1
+        args.frames_per_step = 256 if light else 64
+    nframes, nwarm = args.steps * args.frames_per_step, args.warmup * args.frames_per_step  # frames timed / warmed up
     w, h, spp = wl["width"], wl["height"], wl["spp"]
     flags = wl["flags"] | (R.BRUTE_FORCE if args.brute_force else 0)
     tile = 64 if world == 1 else 32  # several ranks: 32-pixel tiles spread the hit pixels more evenly (1.16 vs 1.62 max/mean at 8)
