@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--composite-frames", type=int, default=8, choices=range(1, 9),
                     help="N > 1, sparse composite: frames per submission and per gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
+                    help="wall time the CPU oracle is given for its whole frames (the bounded sample of the baseline)")
     ap.add_argument("--no-extra-passes", action="store_true",
                     help="skip the passes after the timed region (roofline.alone, roofline.infinity_cache_resident): "
                          "under a profiler the kernel statistics then cover the timed region and its warm-up only")
@@ -638,7 +640,8 @@ def main():
             result["extra_workloads"] = extra
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
-            base, oracle_out, work = cpu_baseline(wl, cams[(nframes - 1) % len(cams)] if turntable else cam)
+            base, oracle_out, work = cpu_baseline(wl, cams[(nframes - 1) % len(cams)] if turntable else cam,
+                                                  budget_s=args.cpu_baseline_seconds)
             # outputs are compared before the timing is accepted
             got = planes.cpu().numpy()
             ok = (np.array_equal(got[2].view(np.uint32).reshape(h, w), oracle_out[2])
