@@ -33,7 +33,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = R.Context(0, stream=stream.cuda_stream)
-    mesh = R.Mesh.load_obj(objfmt.bunny_obj_path())
+    mesh = R.Mesh.load_obj(objfmt.bunny_obj_path()).pin()
     tr = common.grid_translations(a.side)
     times = []
     for rep in range(a.builds):
