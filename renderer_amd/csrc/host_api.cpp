@@ -523,11 +523,15 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         d.triC = keep.take<float>((size_t)d.ntri * 16);
         // with a tree the assembled triangles are scratch: the build stores them again in Morton order
         // (as 48-byte records: the gather into Morton order then pulls one or two cache lines per triangle, not three)
-        float* records = tree ? scratch.take<float>((size_t)d.ntri * 48) : nullptr;
+        // (a mesh of up to 2 MB stays in every XCD's 4 MB L2 while the kernels that read it run: the build then
+        // assembles a triangle again wherever it needs one, and the records are not stored at all)
+        const bool cached_mesh = (size_t)nv * 16 + (size_t)base_ntri * 12 <= (size_t)2 << 20;
+        const bool stored = !(tree && cached_mesh);
+        float* records = tree && stored ? scratch.take<float>((size_t)d.ntri * 48) : nullptr;
         float* bounds = tree ? lbvh_take_bounds(scratch, d.ntri) : nullptr;
-        float* A0 = tree ? records : d.triA;
-        float* B0 = tree ? records + 4 : d.triB;
-        float* C0 = tree ? records + 8 : d.triC;
+        float* A0 = !stored ? nullptr : tree ? records : d.triA;
+        float* B0 = !stored ? nullptr : tree ? records + 4 : d.triB;
+        float* C0 = !stored ? nullptr : tree ? records + 8 : d.triC;
         float* d_tr = nullptr;
         if (translations_xyz) {
             d_tr = scratch.take<float>((size_t)ninst * 12);
@@ -537,8 +541,6 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0, tree ? 3u : 1u, bounds)) != hipSuccess)
             return bail(e, "assemble kernel");
         if (ctx->build_sort_ntri != d.ntri) ctx->build_sort_hint = 0, ctx->build_sort_ntri = d.ntri;
-        // (a mesh of up to 2 MB stays in every XCD's 4 MB L2 while the kernels that read it run)
-        const bool cached_mesh = (size_t)nv * 16 + (size_t)base_ntri * 12 <= (size_t)2 << 20;
         const MeshSource mesh_src = {cached_mesh ? (const float4*)d.xyzw : nullptr, d.idx, d_tr, base_ntri, ninst};
         if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds, mesh_src, &ctx->build_sort_hint)) != hipSuccess) return bail(e, "LBVH build");
     }

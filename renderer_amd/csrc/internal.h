@@ -125,7 +125,8 @@ struct MeshSource {
 // Triangle g's three 16-byte items go to A[g * stride], B[g * stride], C[g * stride] (in float4 units): stride 1
 // fills three arrays, stride 3 with B = A + 4 floats and C = A + 8 floats one array of 48-byte records.
 // `bounds` (or null): bounds_blocks_for(triangles) entries of six floats, the box of a share of the triangles each
-// (lo xyz, hi xyz), for build_lbvh.
+// (lo xyz, hi xyz), for build_lbvh.  A, B and C may be null with `bounds`: the records are then worked out for the
+// bounds only and stored nowhere (a build that assembles them again from a cached mesh wherever it needs them).
 inline uint32_t bounds_blocks_for(uint32_t n) { return n / 256u + 1u < 2048u ? n / 256u + 1u : 2048u; }
 hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const uint32_t* idx, uint32_t base_ntri,
                            const float* translations, uint32_t ninst, float* A, float* B, float* C, uint32_t stride,
@@ -177,8 +178,9 @@ size_t lbvh_scratch_bytes(uint32_t ntri);
 float* lbvh_take_bounds(Arena& scratch, uint32_t n);
 // `sort_hint` (or null): where in the build's list of sorts, shortest first, this build starts and where it ended
 // (0 to begin with; the caller keeps it from build to build).
-// `mesh`: what the records were assembled from, when that is small enough to stay in every L2 (the Morton keys
-// are then made from it instead of from the records: a pass less over the triangles), or a MeshSource without arrays.
+// `mesh`: what the records were assembled from, when that is small enough to stay in every L2 (the Morton keys and
+// the sorted triangle arrays are then made from it instead of from the records, and `records` may be null: the
+// assembled records are neither written nor read), or a MeshSource without arrays.
 hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& scratch, const float* records, const float* bounds,
                       const MeshSource& mesh, int* sort_hint);
 

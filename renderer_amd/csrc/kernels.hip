@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_assemble(MeshSource m, float4* __restri
         float4 ra, rb, rc;
         assemble_record(m, g, ra, rb, rc);
         const uint64_t at = g * stride;
-        A[at] = ra, B[at] = rb, C[at] = rc;
+        if (A) A[at] = ra, B[at] = rb, C[at] = rc; // (no arrays: only the bounds are wanted, see launch_assemble)
         if (bounds) {
             float l[3], h[3];
             tri_box(ra, rb, rc, l, h);

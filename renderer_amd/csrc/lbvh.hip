@@ -448,7 +448,7 @@ __device__ __forceinline__ uint32_t boundary_slot(uint32_t index, uint2 leaves, 
 }
 
 
-__global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restrict__ T0, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restrict__ T0, MeshSource mesh, const uint32_t* __restrict__ order,
                                                          uint32_t* __restrict__ slot_of, float4* __restrict__ TA,
                                                          float4* __restrict__ TB, float4* __restrict__ TC,
                                                          const uint32_t* __restrict__ child,
@@ -487,8 +487,16 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
         // The gather into sorted order happens here, on the way: the triangle at sorted position i is the assembled
         // record order[i].  (A kernel of its own for it read the records, wrote them sorted, and this one read them
         // again: a sixth of a five-million-triangle build.)
-        const float4* rec = T0 + 3 * (size_t)src;
-        const float4 a = rec[0], b = rec[1], c = rec[2];
+        // With `mesh` (one that the caches hold) the record is assembled again from it, the same floats: the assembled
+        // records are then never stored at all, which saves writing 48 bytes per triangle and fetching them here from
+        // all over memory.
+        float4 a, b, c;
+        if (mesh.xyzw) { // (the same for every lane)
+            assemble_record(mesh, src, a, b, c);
+        } else {
+            const float4* rec = T0 + 3 * (size_t)src;
+            a = rec[0], b = rec[1], c = rec[2];
+        }
         TA[i] = a, TB[i] = b, TC[i] = c;
         slot_of[src] = i; // the inverse of `order`: primitive id -> sorted position
         float lo[3], hi[3];
@@ -977,7 +985,7 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     uint32_t* fine_count = words + kWFineCount;
-    hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, (const uint32_t*)sc.order, sc.slot_of, A1, B1,
+    hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, mesh, (const uint32_t*)sc.order, sc.slot_of, A1, B1,
                        C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
                        words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
     // the nodes that cross chunk boundaries: a workgroup per span of chunks as far as the spans go, one for the rest
