@@ -448,7 +448,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
     const bool tree = d.ntri >= 2;
     Arena keep, scratch;
     keep.size = Arena::aligned((size_t)nv * 16) + Arena::aligned((size_t)base_ntri * 12) + 3 * tri_bytes +
-                lbvh_keep_bytes(d.ntri) + 256;
+                lbvh_keep_bytes(d.ntri) + Arena::aligned((size_t)ninst * 12) + 256;
     scratch.size = (tree ? Arena::aligned((size_t)d.ntri * 48) + lbvh_scratch_bytes(d.ntri) : 0) + Arena::aligned((size_t)ninst * 12) + 256;
     int rc = INV_OK;
     hipError_t e = hipSuccess;
@@ -534,7 +534,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         float* C0 = !stored ? nullptr : tree ? records + 8 : d.triC;
         float* d_tr = nullptr;
         if (translations_xyz) {
-            d_tr = scratch.take<float>((size_t)ninst * 12);
+            d_tr = keep.take<float>((size_t)ninst * 12); // (kept: draws of a cached mesh assemble triangles from it too)
             if ((e = hipMemcpyAsync(d_tr, translations_xyz, (size_t)ninst * 12, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
                 return bail(e, "hipMemcpyAsync(translations)");
         }
@@ -542,6 +542,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
             return bail(e, "assemble kernel");
         if (ctx->build_sort_ntri != d.ntri) ctx->build_sort_hint = 0, ctx->build_sort_ntri = d.ntri;
         const MeshSource mesh_src = {cached_mesh ? (const float4*)d.xyzw : nullptr, d.idx, d_tr, base_ntri, ninst};
+        d.translations = d_tr, d.base_ntri = base_ntri, d.ninst = ninst, d.mesh_cached = cached_mesh;
         if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds, mesh_src, &ctx->build_sort_hint)) != hipSuccess) return bail(e, "LBVH build");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize(scene build)");

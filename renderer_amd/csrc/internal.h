@@ -111,6 +111,12 @@ struct DeviceScene {
     bool has_bvh = false;
     uint32_t height = 0;           // height of the root (a node over two leaves has height 1)
     float bbox[6] = {0, 0, 0, 0, 0, 0};
+    // What the triangles were assembled from, for kernels that assemble a triangle again instead of fetching its
+    // record (see MeshSource): the instances' translations (xyz each; null: one instance, not moved), the triangles of
+    // one instance, the instances, and whether the mesh is small enough to stay in the caches.
+    float* translations = nullptr;
+    uint32_t base_ntri = 0, ninst = 1;
+    bool mesh_cached = false;
 };
 
 hipError_t launch_vertex_shader(hipStream_t s, const float* xyzw, uint32_t nv, const inv_camera& cam, float* clip4,

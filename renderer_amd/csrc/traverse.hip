@@ -1690,8 +1690,10 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
 // kernel computes) and offers its (depth, primitive) key to the pixel's entry of a visibility buffer with a 64-bit
 // atomic minimum: the depth test LESS with the lower primitive winning ties (src/invert.cpp:1384 + draw order), and
 // independent of the order in which triangles arrive.  A second pass reads each pixel's winner, looks up where that
-// primitive sits in the sorted arrays, repeats the test once for the barycentric terms, shades and stores, and puts
-// the entry back to the miss key for the next frame.
+// primitive sits in the sorted arrays (or, when the scene was made from a mesh small enough for the caches, assembles
+// the triangle again from that mesh: two fetches that the L2 answers instead of a chain of three all over memory),
+// repeats the test once for the barycentric terms, shades and stores, and puts the entry back to the miss key for the
+// next frame.
 // Which pixels a triangle must try: a triangle that passes the test at a pixel has its hit point inside its own box
 // grown by one guard pad, and that point projects to the pixel centre (to within the roundings of this projection and
 // of the ray's inverse matrix: about 10^-3 pixel at the largest extents the API accepts); so the centre lies in the
@@ -1719,6 +1721,8 @@ __device__ __forceinline__ void scatter_pair(const FrameK& f, uint32_t k, uint32
 // test.  (All in one loop per triangle, a wave ran the full test once per loop trip for whichever lanes had a
 // candidate in that trip, and everything behind the back-face test with half its lanes: 760 wave-instructions per
 // wave at 42 % of lanes.)
+// (Assembling the triangles again from a mesh that the caches hold, as the resolve pass does with its winners, was
+// no faster here: 72 against 71 us for five million triangles.  The pass is not waiting for its 48 bytes per triangle.)
 __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float4* __restrict__ TA,
                                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                            uint32_t ntri, unsigned long long* __restrict__ vis) {
@@ -1845,7 +1849,7 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
 
 // One lane per output pixel: the winner of the pixel's visibility entry is shaded and stored, and the entry is put
 // back to the miss key.  `slot_of`: primitive id -> position in the sorted triangle arrays.
-__global__ __launch_bounds__(256) void k_scatter_resolve(FrameK f, const float4* __restrict__ TA,
+__global__ __launch_bounds__(256) void k_scatter_resolve(FrameK f, MeshSource mesh, const float4* __restrict__ TA,
                                                          const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                          const uint32_t* __restrict__ slot_of, uint32_t ntri,
                                                          unsigned long long* __restrict__ vis, AoK ao, Outputs out) {
@@ -1863,9 +1867,15 @@ __global__ __launch_bounds__(256) void k_scatter_resolve(FrameK f, const float4*
         const unsigned long long key = vis[pix];
         if (key != kMissKey) vis[pix] = kMissKey;
         if (key != kMissKey && (uint32_t)key < ntri) { // (the second test never fails for keys the first pass wrote)
-            const uint32_t slot = slot_of[(uint32_t)key];
-            const float4 A = TA[slot];
-            Bw = TB[slot], Cw = TC[slot];
+            // (with a cached mesh the winner is assembled again from it: no look-up of its place in the sorted arrays)
+            uint32_t slot = 0u;
+            float4 A;
+            if (mesh.xyzw) {
+                assemble_record(mesh, (uint32_t)key, A, Bw, Cw);
+            } else {
+                slot = slot_of[(uint32_t)key];
+                A = TA[slot], Bw = TB[slot], Cw = TC[slot];
+            }
             mt_test(f, ray0, A, Bw, Cw, slot, first); // the same test again: the same key, now with its terms
             if (first.key != kMissKey) shade_hit(f, first, A, Bw, Cw, r, g, b);
         }
@@ -1883,7 +1893,7 @@ __global__ __launch_bounds__(256) void k_scatter_resolve(FrameK f, const float4*
 // The same for whole row-major frames whose rows and buffers allow 16-byte accesses, without an occlusion pass: four
 // pixels of a row per lane, 16 bytes per attachment and store (write-through and non-temporal, like the clear: five
 // sixths of these pixels are background).
-__global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, const float4* __restrict__ TA,
+__global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, MeshSource mesh, const float4* __restrict__ TA,
                                                           const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                           const uint32_t* __restrict__ slot_of, uint32_t ntri,
                                                           unsigned long long* __restrict__ vis, Outputs out) {
@@ -1926,12 +1936,17 @@ __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, const float4
 #pragma unroll
             for (int j = 0; j < G; j++) {
                 hit[j] = keys[j0 + j] != kMissKey && (uint32_t)keys[j0 + j] < ntri; // (the second test never fails for keys the first pass wrote)
-                slot[j] = hit[j] ? slot_of[(uint32_t)keys[j0 + j]] : 0u;
+                slot[j] = hit[j] && !mesh.xyzw ? slot_of[(uint32_t)keys[j0 + j]] : 0u;
             }
             float4 A[G], B[G], C[G];
 #pragma unroll
             for (int j = 0; j < G; j++)
-                if (hit[j]) A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]];
+                if (hit[j]) {
+                    if (mesh.xyzw) // (the same for every lane) the winner assembled again from the cached mesh
+                        assemble_record(mesh, (uint32_t)keys[j0 + j], A[j], B[j], C[j]);
+                    else
+                        A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]];
+                }
 #pragma unroll
             for (int j = 0; j < G; j++) {
                 float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
@@ -2369,6 +2384,14 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         return hipGetLastError();
     }
     if (vis && scatter_wanted(f, sc, out)) {
+        // a mesh that the caches hold: the resolve pass assembles the winners from it instead of looking them up in the
+        // sorted arrays (INV_MESH_DRAW=0 in the environment: never; for measurements)
+        static const bool mesh_draw = [] {
+            const char* e = std::getenv("INV_MESH_DRAW");
+            return !(e && e[0] == '0');
+        }();
+        const MeshSource mesh = {sc.mesh_cached && mesh_draw ? (const float4*)sc.xyzw : nullptr, sc.idx, sc.translations,
+                                 sc.base_ntri, sc.ninst};
         // (nothing to try when the scene lies outside the frame: the resolve pass then stores clear values only)
         if (f.rx1 > f.rx0 && f.ry1 > f.ry0)
             hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 256u * kScatterPerLane - 1u) / (256u * kScatterPerLane)), dim3(256), 0, s, f, (const float4*)sc.triA,
@@ -2381,11 +2404,11 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
 #else
             const unsigned resolve_blocks = (unsigned)((f.npix / 4 + 255) / 256);
 #endif
-            hipLaunchKernelGGL(k_scatter_resolve4, dim3(resolve_blocks), dim3(256), 0, s, f,
+            hipLaunchKernelGGL(k_scatter_resolve4, dim3(resolve_blocks), dim3(256), 0, s, f, mesh,
                                (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
                                (const uint32_t*)sc.slot_of, sc.ntri, vis, out);
         } else
-            hipLaunchKernelGGL(k_scatter_resolve, dim3((unsigned)((f.npix + 255) / 256)), dim3(256), 0, s, f,
+            hipLaunchKernelGGL(k_scatter_resolve, dim3((unsigned)((f.npix + 255) / 256)), dim3(256), 0, s, f, mesh,
                                (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
                                (const uint32_t*)sc.slot_of, sc.ntri, vis, ao, out);
         return hipGetLastError();
