@@ -154,6 +154,9 @@ uint32_t tile_bins_wanted(const FrameK& f, const DeviceScene& sc, const Outputs&
 // kernels leave it that way), for frames drawn one lane per triangle (scatter_wanted); null: such frames go through
 // the tile kernel like any other.
 bool scatter_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out);
+// Whether the resolve pass of such frames assembles its winners again from a mesh that the caches hold (always,
+// unless INV_MESH_DRAW=0 in the environment): the build then leaves `slot_of` out, which only that pass would read.
+bool mesh_draw_enabled();
 hipError_t launch_vis_fill(hipStream_t s, unsigned long long* vis, uint64_t n);
 hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& sc, const AoK& ao, const Outputs& out,
                              const BinMem* bins, unsigned long long* vis);

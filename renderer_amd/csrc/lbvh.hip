@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
             a = rec[0], b = rec[1], c = rec[2];
         }
         TA[i] = a, TB[i] = b, TC[i] = c;
-        slot_of[src] = i; // the inverse of `order`: primitive id -> sorted position
+        if (slot_of) slot_of[src] = i; // the inverse of `order`: primitive id -> sorted position (null: nobody will ask)
         float lo[3], hi[3];
         tri_box(a, b, c, lo, hi);
 #pragma unroll
@@ -985,6 +985,9 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
                        range);
     uint32_t* fine_count = words + kWFineCount;
+    // (the inverse order is a scatter of four bytes per triangle all over memory, and only the resolve pass of frames
+    // drawn one lane per triangle reads it -- unless it assembles its winners from the cached mesh)
+    if (mesh.xyzw && mesh_draw_enabled()) sc.slot_of = nullptr;
     hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, mesh, (const uint32_t*)sc.order, sc.slot_of, A1, B1,
                        C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
                        words + kWFinishedChunks, sc.fine, fine_count, fine_cap);

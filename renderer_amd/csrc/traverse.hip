@@ -2350,8 +2350,17 @@ static int scatter_env() {
     return v;
 }
 
+bool mesh_draw_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("INV_MESH_DRAW");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 bool scatter_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out) {
-    if (f.npix == 0 || !sc.has_bvh || !sc.slot_of || f.spp != 1u) return false;
+    // (the resolve pass finds a winner's triangle through slot_of or in the cached mesh)
+    if (f.npix == 0 || !sc.has_bvh || !(sc.slot_of || (sc.mesh_cached && mesh_draw_enabled())) || f.spp != 1u) return false;
     if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE | INV_BLOCKS)) return false;
     const int env = scatter_env();
     if (env == 0 || !eye_outside_scene(f, sc)) return false;
@@ -2386,12 +2395,8 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     if (vis && scatter_wanted(f, sc, out)) {
         // a mesh that the caches hold: the resolve pass assembles the winners from it instead of looking them up in the
         // sorted arrays (INV_MESH_DRAW=0 in the environment: never; for measurements)
-        static const bool mesh_draw = [] {
-            const char* e = std::getenv("INV_MESH_DRAW");
-            return !(e && e[0] == '0');
-        }();
-        const MeshSource mesh = {sc.mesh_cached && mesh_draw ? (const float4*)sc.xyzw : nullptr, sc.idx, sc.translations,
-                                 sc.base_ntri, sc.ninst};
+        const MeshSource mesh = {sc.mesh_cached && mesh_draw_enabled() ? (const float4*)sc.xyzw : nullptr, sc.idx,
+                                 sc.translations, sc.base_ntri, sc.ninst};
         // (nothing to try when the scene lies outside the frame: the resolve pass then stores clear values only)
         if (f.rx1 > f.rx0 && f.ry1 > f.ry0)
             hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 256u * kScatterPerLane - 1u) / (256u * kScatterPerLane)), dim3(256), 0, s, f, (const float4*)sc.triA,
