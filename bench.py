@@ -38,6 +38,69 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+
+def _launch_ranks():
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks from here.
+
+    This runs before torch, the library or anything else that could open the GPU is imported: the parent only starts
+    N fresh interpreters of this file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, as
+    torch.distributed.run would), passes rank 0's standard output through (the one JSON line), sends the other
+    ranks' standard output to standard error, and exits with the worst status.  A rank that fails takes the others
+    down with it (they would wait in a collective for ever).  Returns None when there is nothing to launch."""
+    if "WORLD_SIZE" in os.environ:
+        return None
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args()
+    if known.gpus <= 1 or any(a in ("-h", "--help") for a in sys.argv[1:]):
+        return None
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(known.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(known.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), INV_BENCH_LAUNCHED_BY=str(os.getpid()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst, failed_at = 0, None
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            for r, p in enumerate(procs):
+                rc = p.poll()
+                if rc not in (None, 0) and failed_at is None:
+                    failed_at = time.monotonic()
+                    print("bench.py: rank %d exited with status %d; stopping the other ranks" % (r, rc), file=sys.stderr)
+            if failed_at is not None and time.monotonic() - failed_at > 5.0:  # the others had their chance to follow
+                for p in procs:
+                    if p.poll() is None:
+                        p.send_signal(signal.SIGTERM)
+                failed_at = float("inf")
+    except KeyboardInterrupt:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+    for p in procs:
+        try:
+            rc = p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = p.wait()
+        if rc != 0:
+            worst = max(worst, rc if rc > 0 else 128 - rc)
+    return worst
+
+
+if __name__ == "__main__":
+    _status = _launch_ranks()
+    if _status is not None:
+        sys.exit(_status)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -122,7 +185,9 @@ def cpu_baseline(wl, camera, budget_s=10.0):
     w, h = wl["width"], wl["height"]
     cam = O.Camera.from_buffer_copy(bytes(camera))  # the same 204 bytes the GPU drew with
     prm = O.make_params(w, h, spp=wl["spp"], flags=wl["flags"], ao_rays=wl.get("ao_rays", 0))
-    cores = min(16, os.cpu_count() or 1)
+    # threads used: the box gives one GPU's job a share of 16 CPUs, whatever the machine has (cores_present)
+    cores_present = os.cpu_count() or 1
+    cores = min(16, cores_present)
     cnt = O.Counters()
     O.render_bvh(xyzw, idx, cam, prm, nthreads=cores, counters=cnt)  # warm; also counts the traversal's tests
     frames, t0 = 0, time.perf_counter()
@@ -135,7 +200,7 @@ def cpu_baseline(wl, camera, budget_s=10.0):
     hits = int((out[2] != 0xFFFFFFFF).sum())
     rays = (w * h * wl["spp"] + wl.get("ao_rays", 0) * hits) * frames
     flops = (FLOPS_RAY * cnt.rays + FLOPS_BOX * cnt.box_tests + FLOPS_TRI * cnt.tri_tests + FLOPS_SHADE * cnt.hits)
-    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, cores_present=cores_present, kind="port",
                 sample="%d whole %dx%d frames (%d spp) through the oracle's CPU LBVH, %d threads, %.1f s"
                        % (frames, w, h, wl["spp"], cores, dt)), out, dict(
         rays=int(cnt.rays), box_tests=int(cnt.box_tests), tri_tests=int(cnt.tri_tests), hits=int(cnt.hits), flops=int(flops))
@@ -190,13 +255,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+    if world != args.gpus:  # (without WORLD_SIZE and with --gpus N > 1 the ranks were started by _launch_ranks above)
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to time")
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d over RCCL needs %d GPUs, this node shows %d (--backend gloo rehearses the ranks on one GPU)"
+                         % (world, world, torch.cuda.device_count()))
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -334,18 +399,21 @@ def main():
     def make_groups(nframes):
         return [(g % 2, min(fpl, nframes - g * fpl)) for g in range((nframes + fpl - 1) // fpl)]
 
+    def composite_group(cb, k, n):
+        if direct:
+            cb.composite(k, n)
+        else:  # rehearsal: the collective runs on host copies
+            ctx.frames_join()
+            if cb.slot_elems:
+                host = RD.gather_to_rank0(cb.planes[k][:n].cpu(), rank, world)
+                if rank == 0:
+                    cb.gathered[k][:, :n].copy_(host)
+            cb.scatter_received(k, n)
+
     def run_groups(groups):
         for k, n in groups:
             cb.render(k, n)
-            if direct:
-                cb.composite(k, n)
-            else:  # rehearsal: the collective runs on host copies
-                ctx.frames_join()
-                if cb.slot_elems:
-                    host = RD.gather_to_rank0(cb.planes[k][:n].cpu(), rank, world)
-                    if rank == 0:
-                        cb.gathered[k][:, :n].copy_(host)
-                cb.scatter_received(k, n)
+            composite_group(cb, k, n)
 
     if grouped:
         slot_streams = cb.slot_streams
@@ -475,74 +543,94 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    # Several ranks: the headline frame is bound by rank 0's own stores, so sharding cannot pay there; these short
-    # passes (not part of `value`) time the heavier workloads the same way: the sharded draw alone, the draw plus the
-    # composite, and the whole frame on one GPU (rank 0 alone, the others idle), max over ranks.
-    extra = {}
+    # Several ranks: the headline frame is bound by rank 0's own stores (every pixel of every frame is written into
+    # rank 0's HBM whatever N is), so sharding cannot pay there; these short passes (not part of `value`) time the
+    # timed workload and the two heavier ones the same way, as a stream of frames in groups of `xf` per submission
+    # and per gather on two buffer sets: the sharded draws alone, the draws plus the composite, and the whole frames
+    # on one GPU (rank 0 alone on two frame slots, the others idle); per frame, max over ranks.
+    extra, scaling_workloads = {}, {}
     if world > 1 and sparse and not args.no_extra_workloads:
-        for name in ("bunny_4k_16spp", "bunny_1080p_ao64_closeup"):
+        rehearsal = args.backend != "nccl"  # ranks sharing one GPU: enough frames to see that it works
+
+        def timed(body, n, frames_each):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_0 = time.perf_counter()
+            for i in range(n):
+                body(i)
+            ctx.frames_join()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt[0]) / (n * frames_each) * 1e3
+
+        names = [args.workload] + [n_ for n_ in ("bunny_4k_16spp", "bunny_1080p_ao64_closeup") if n_ != args.workload]
+        for name in names:
             xw = WORKLOADS[name]
+            if xw.get("instances_side", 1) != side or xw.get("turntable"):
+                continue  # another scene than the one built
             ew, eh = xw["width"], xw["height"]
             ecam = R.camera_reference(ew, eh)
+            if side > 1:
+                ecam = common.pulled_back_camera(ecam, 0.27 * side)
             if "view_translation" in xw:
                 ecam.view[12], ecam.view[13], ecam.view[14] = xw["view_translation"]
+            kw = dict(spp=xw["spp"], flags=xw["flags"], ao_rays=xw.get("ao_rays", 0))
+            heavy = bool(kw["ao_rays"]) or ew * eh * kw["spp"] > 1 << 26
+            xf = (2 if rehearsal else 4) if heavy else (4 if rehearsal else 8)  # frames per group
+            n_x = 2 if rehearsal else (6 if heavy else 24)                      # groups timed
+            # the whole frames on one GPU: rank 0 alone, groups of xf frames on two frame slots in turn
+            eprm = R.make_params(ew, eh, **kw)
+            one_ms, one = None, None
+            if rank == 0:
+                one = torch.empty(2, xf, 3, eh * ew, dtype=torch.int32, device="cuda")
+                one_batches = [scene.make_batch([ecam] * xf, [eprm] * xf,
+                                                [tuple(one[j, u, p_].data_ptr() for p_ in range(3)) for u in range(xf)])
+                               for j in range(2)]
+
+            def alone(i):
+                if rank == 0:
+                    scene.render_batch(one_batches[i % 2], i % 2)
+
+            alone(0)
+            alone(1)
+            one_ms = timed(alone, n_x, xf)
             for share, share_flag in [("equal", 0)] + ([("rank0_idle", R.ROOT_IDLE)] if world >= 3 else []):
-                kw = dict(spp=xw["spp"], flags=xw["flags"], ao_rays=xw.get("ao_rays", 0))
-                esc = RD.SparseComposite(scene, ecam, ew, eh, rank, world, tile=32, comm=comm,
-                                         **dict(kw, flags=kw["flags"] | share_flag))
+                ecb = RD.SparseCompositeBatch(scene, ecam, ew, eh, rank, world, frames=xf, sets=2, tile=32, comm=comm,
+                                              **dict(kw, flags=kw["flags"] | share_flag))
 
-                def composite_once():
-                    if direct:
-                        esc.composite()
-                    elif esc.slot_elems:  # rehearsal: the collective runs on host copies
-                        stream.synchronize()
-                        host = RD.gather_to_rank0(esc.planes.cpu(), rank, world)
-                        if rank == 0:
-                            esc.gathered.copy_(host)
-                        esc.scatter_received()
+                def draws(i):
+                    ecb.render(i % 2, xf)
 
-                def timed(body, n):
-                    torch.cuda.synchronize()
-                    dist.barrier()
-                    t_0 = time.perf_counter()
-                    for _ in range(n):
-                        body()
-                    torch.cuda.synchronize()
-                    tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    return float(tt[0]) / n * 1e3
+                def both(i):
+                    ecb.render(i % 2, xf)
+                    composite_group(ecb, i % 2, xf)
 
-                def both():
-                    esc.render()
-                    composite_once()
-
-                rehearsal = args.backend != "nccl"  # ranks sharing one GPU: enough frames to see that it works
-                for _ in range(1 if rehearsal else 3):
-                    both()
-                n_x = 4 if rehearsal else 20
-                render_ms = timed(esc.render, n_x)
-                both_ms = timed(both, n_x)
-                one = torch.empty(3, eh * ew, dtype=torch.int32, device="cuda") if rank == 0 else None
-                eprm = R.make_params(ew, eh, **kw)
-
-                def alone():
-                    if rank == 0:
-                        scene.render_device(ecam, eprm, one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr())
-
-                alone()
-                one_ms = timed(alone, n_x)
-                both()
+                for i in range(2):
+                    both(i)
+                render_ms = timed(draws, n_x, xf)
+                both_ms = timed(both, n_x, xf)
+                both(0)
+                ctx.frames_join()
                 torch.cuda.synchronize()
-                ok = bool(torch.equal(one, esc.frame)) if rank == 0 else True
+                ok = all(bool(torch.equal(one[0, 0], ecb.frames[0][u])) for u in range(xf)) if rank == 0 else True
                 res = {"render_only_ms": render_ms, "render_plus_gather_ms": both_ms, "one_gpu_ms": one_ms,
-                       "composite_equals_one_gpu_frame": ok, "frames_timed": n_x}
+                       "composite_equals_one_gpu_frame": ok, "frames_timed": n_x * xf, "frames_per_gather": xf}
                 if rank == 0 and not ok:
                     raise SystemExit("extra workload %s (%s): the composite differs from the single-GPU frame" % (name, share))
                 if share == "equal":
                     extra[name] = res
                 else:  # the same with rank 0 drawing no tiles
                     extra[name][share] = {k: res[k] for k in ("render_only_ms", "render_plus_gather_ms", "composite_equals_one_gpu_frame")}
-                del esc, one
+                del ecb
+            del one
+            # the summary the scaling curve is read from: per frame, the better of the two shares of rank 0
+            best = min([("equal", extra[name])] + ([("none", extra[name]["rank0_idle"])] if "rank0_idle" in extra[name] else []),
+                       key=lambda sv: sv[1]["render_plus_gather_ms"])
+            scaling_workloads[name] = {
+                "one_gpu_ms": one_ms, "render_only_ms": best[1]["render_only_ms"],
+                "render_plus_gather_ms": best[1]["render_plus_gather_ms"], "root_share": best[0], "frames_per_gather": xf,
+                "speedup_over_one_gpu": one_ms / best[1]["render_plus_gather_ms"], "n_gpus": world}
 
     if world > 1 and rank == 0:
         # the composite must equal the same frame rendered by this rank alone
@@ -618,7 +706,10 @@ def main():
                          # one launch of the kernel: a slot's span between two HIP events on its stream / its launches;
                          # with several slots a launch shares the GPU with the other slots' launches
                          "launch": {"kernel_ms": kernel_ms, "concurrent_launches": fif if slots_used else 1,
-                                    "achieved": achieved, "frac": achieved / HBM_PEAK_GBS}},
+                                    "achieved": achieved, "frac": achieved / HBM_PEAK_GBS},
+                         # `frac` is the job's (launches of several slots overlap); one launch on its own reaches
+                         # per_launch_frac (the replay of the same submissions on one slot, roofline.alone)
+                         "per_launch_frac": None},
             "cpu_baseline": None,
         }
         set_mb = 12 * (w * h) / 1e6
@@ -634,11 +725,16 @@ def main():
         if alone_ms is not None:  # the same launches when no other slot's launch shares the GPU with them
             result["roofline"]["alone"] = {"kernel_ms": alone_ms, "achieved": launch_bytes / (alone_ms * 1e-3) / 1e9,
                                            "frac": launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            result["roofline"]["per_launch_frac"] = result["roofline"]["alone"]["frac"]
+        else:
+            result["roofline"]["per_launch_frac"] = achieved / HBM_PEAK_GBS
         # VALU side: utilisation from the newest committed rocprofv3 counter pass of this workload (the counters
         # cannot be read inside this process), or None
         result["roofline"]["valu"] = pmc_valu(args.workload, world, kernel_name.split("+")[-1])
+        valu_bound = bool(ao_rays) or spp >= 4  # occlusion rays and many samples per pixel: vector arithmetic, not stores
         if extra:
             result["extra_workloads"] = extra
+            result["scaling_workloads"] = scaling_workloads
         if world == 1 and not args.no_cpu_baseline:
             # (turntable: the frame left in the buffers is the last step's)
             base, oracle_out, work = cpu_baseline(wl, cams[(nframes - 1) % len(cams)] if turntable else cam,
@@ -656,6 +752,21 @@ def main():
             # counts: 20 flops per ray, 22 per box test, 51 per triangle test, 15 per shaded hit), for comparison with
             # the instruction counts of the kernel's counter pass
             result["cpu_baseline"]["oracle_traversal_work"] = work
+        if valu_bound:
+            # The frame is bound by vector arithmetic: the roofline is the fp32 vector peak.  `achieved` = the
+            # algorithmic flops of a per-ray LBVH traversal of this frame (the oracle's own test counts: 20 per ray,
+            # 22 per box test, 51 per triangle test, 15 per shaded hit) over this run's time per frame; what the
+            # kernel's counter pass saw (issue slots, active lanes) stays under roofline.valu, and the HBM view of
+            # the same run is kept beside it.
+            r = result["roofline"]
+            hbm_view = {k: r[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes", "traffic")}
+            flops = basis = None
+            if result["cpu_baseline"]:
+                flops, basis = float(result["cpu_baseline"]["oracle_traversal_work"]["flops"]), "algorithmic flops of the oracle's traversal of this frame"
+            if flops:
+                tf = flops * nframes / elapsed / 1e12
+                r.update({"bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
+                          "flops_per_frame": flops, "flops_basis": basis, "hbm": hbm_view})
         print(json.dumps(result))
     if comm is not None:
         comm.close()

@@ -272,7 +272,10 @@ int inv_deinterleave_sparse(inv_ctx* ctx, const inv_params* params, const uint32
  *                         if it cannot be).
  *   inv_comm_create_host  staging through files in directory `dir`, which every rank must reach (/dev/shm on one
  *                         node): for rehearsing the several-rank path where RCCL cannot run (it refuses two ranks on one
- *                         GPU), and as a fallback.  Blocking: the call returns when the data has arrived. */
+ *                         GPU), and as a fallback.  Blocking: the call returns when the data has arrived.  Give every
+ *                         communicator a fresh directory of its own (mkdtemp): files are named by exchange number and
+ *                         rank, and each carries a header (exchange, rank, rank count, element count) that rank 0
+ *                         checks, so a file left by another run is refused (INV_ERR_IO), not taken for tiles. */
 typedef struct inv_comm inv_comm;
 #define INV_COMM_ID_BYTES 128
 enum { INV_COMM_RCCL = 0, INV_COMM_HOST = 1 };

@@ -198,6 +198,11 @@ int inv_comm_gather(inv_comm* comm, const void* send, uint64_t count, void* recv
         return comm->dir + name;
     };
     comm->host.resize((size_t)count);
+    // every file starts with what it is: a file of another exchange, another communicator's size or an older run
+    // left in the directory is refused instead of being taken for this exchange's tiles
+    const auto header = [&](uint32_t rank, uint64_t out[4]) {
+        out[0] = 0x31564e49484d4f43ull /* "COMHINV1" */, out[1] = seq, out[2] = ((uint64_t)comm->nranks << 32) | rank, out[3] = count;
+    };
     if (comm->rank != 0) {
         if (hipMemcpyAsync(comm->host.data(), send, (size_t)count * 4, hipMemcpyDeviceToHost, comm->stream) != hipSuccess ||
             hipStreamSynchronize(comm->stream) != hipSuccess)
@@ -205,7 +210,9 @@ int inv_comm_gather(inv_comm* comm, const void* send, uint64_t count, void* recv
         const std::string tmp = path(comm->rank, "tmp"), fin = path(comm->rank, "bin");
         FILE* fp = std::fopen(tmp.c_str(), "wb");
         if (!fp) return fail(INV_ERR_IO, "inv_comm_gather: cannot create " + tmp);
-        const size_t wrote = std::fwrite(comm->host.data(), 4, (size_t)count, fp);
+        uint64_t hd[4];
+        header(comm->rank, hd);
+        const size_t wrote = std::fwrite(hd, sizeof hd, 1, fp) == 1 ? std::fwrite(comm->host.data(), 4, (size_t)count, fp) : 0;
         if (std::fclose(fp) != 0 || wrote != (size_t)count) return fail(INV_ERR_IO, "inv_comm_gather: cannot write " + tmp);
         if (std::rename(tmp.c_str(), fin.c_str()) != 0) return fail(INV_ERR_IO, "inv_comm_gather: cannot rename " + tmp);
         return INV_OK;
@@ -220,10 +227,15 @@ int inv_comm_gather(inv_comm* comm, const void* send, uint64_t count, void* recv
         }
         FILE* fp = std::fopen(fin.c_str(), "rb");
         if (!fp) return fail(INV_ERR_IO, "inv_comm_gather: cannot open " + fin);
-        const size_t got = std::fread(comm->host.data(), 4, (size_t)count, fp);
+        uint64_t hd[4], want[4];
+        header(p, want);
+        const bool hd_ok = std::fread(hd, sizeof hd, 1, fp) == 1 && std::memcmp(hd, want, sizeof hd) == 0;
+        const size_t got = hd_ok ? std::fread(comm->host.data(), 4, (size_t)count, fp) : 0;
+        const bool at_end = hd_ok && std::fgetc(fp) == EOF;
         std::fclose(fp);
         (void)::unlink(fin.c_str());
-        if (got != (size_t)count) return fail(INV_ERR_IO, "inv_comm_gather: short file " + fin);
+        if (!hd_ok) return fail(INV_ERR_IO, "inv_comm_gather: " + fin + " is not this exchange's file (left by another run or communicator?)");
+        if (got != (size_t)count || !at_end) return fail(INV_ERR_IO, "inv_comm_gather: " + fin + " has the wrong length");
         if (hipMemcpyAsync((uint32_t*)recv + (size_t)p * rank_stride, comm->host.data(), (size_t)count * 4, hipMemcpyHostToDevice,
                            comm->stream) != hipSuccess ||
             hipStreamSynchronize(comm->stream) != hipSuccess) // the staging vector is reused for the next rank

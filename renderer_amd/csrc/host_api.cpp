@@ -804,17 +804,24 @@ int render_on(inv_scene* scene, hipStream_t stream, FrameScratch& fs, const inv_
         // the first draw of this scene with occlusion rays: the occlusion kernel's four-wide node records, derived
         // from the LBVH once (64 bytes per internal node; the entry point that allocates nothing walks the LBVH's own
         // two-wide records instead).  Other frame slots may draw with them next, so their making is waited for.
+        // The primary kernel has already queued this frame's occlusion records, so nothing here may end the draw:
+        // without the wide records (no memory for them) the occlusion kernel walks the LBVH's own two-wide records,
+        // as it does for the entry point that allocates nothing, with the same counts.
         uint32_t* w = nullptr;
-        HIP_TRY(hipMalloc((void**)&w, (size_t)(scene->d.ntri - 1u) * 64u));
-        hipError_t e = launch_make_wnodes(stream, scene->d, w);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) {
-            (void)hipFree(w);
-            return fail(INV_ERR_HIP, std::string("wide nodes: ") + hipGetErrorString(e));
+        if (hipMalloc((void**)&w, (size_t)(scene->d.ntri - 1u) * 64u) != hipSuccess) {
+            (void)hipGetLastError(); // cleared: the draw goes on
+            w = nullptr;
+        } else {
+            hipError_t e = launch_make_wnodes(stream, scene->d, w);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                (void)hipFree(w);
+                return fail(INV_ERR_HIP, std::string("wide nodes: ") + hipGetErrorString(e));
+            }
+            scene->d.wnodes = w;
         }
-        scene->d.wnodes = w;
     }
-    HIP_TRY(launch_ao(stream, f, scene->d, ao, dev, noalloc));
+    HIP_TRY(launch_ao(stream, f, scene->d, ao, dev, noalloc || (ao.rays && !scene->d.wnodes)));
     if (!out->on_device) {
         if (out->color) HIP_TRY(hipMemcpyAsync(out->color, dev.color, f.npix * 4, hipMemcpyDeviceToHost, stream));
         if (out->depth) HIP_TRY(hipMemcpyAsync(out->depth, dev.depth, f.npix * 4, hipMemcpyDeviceToHost, stream));
@@ -1090,7 +1097,8 @@ int inv_deinterleave(inv_ctx* ctx, const inv_params* params, const void* gathere
     int rc = fill_layout(p, &f);
     if (rc != INV_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    const uint64_t own = (uint64_t)f.slots * f.tile * f.tile;
+    // one drawing rank's buffer (with INV_ROOT_IDLE the layout of rank 0 itself has no slots, the others' do)
+    const uint64_t own = (uint64_t)((f.ntiles + f.nranks - 1) / f.nranks) * f.tile * f.tile;
     if (rank_stride != 0 && rank_stride < own) return fail(INV_ERR_ARG, "inv_deinterleave: rank_stride is smaller than one rank's buffer");
     HIP_TRY(launch_deinterleave(ctx->stream, f, (const uint32_t*)gathered, rank_stride ? rank_stride : own, (uint32_t*)frame));
     return INV_OK;

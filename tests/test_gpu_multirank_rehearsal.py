@@ -69,3 +69,40 @@ def test_bench_with_the_librarys_own_exchange(nranks, extra):
     r = _run(nranks, "--gather", "c", *extra, steps=5, warmup=2)
     assert r["n_gpus"] == nranks and r["config"]["hit_pixels"] == 25139
     assert "inv_comm_gather" in r["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_bench_starts_its_own_ranks(nranks):
+    """`python bench.py --gpus N` without torch.distributed.run and without WORLD_SIZE: the parent starts the N ranks
+    itself (before anything opens the GPU), rank 0's line comes out once, and it carries the per-workload phase times
+    the scaling curve is read from."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--backend", "gloo", "--steps", "3",
+           "--warmup", "1", "--frames-per-step", "2"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=230)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == nranks and r["steps"] == 3 and r["value"] > 0
+    sw = r["scaling_workloads"]
+    assert set(sw) == {"bunny_1080p_primary_lambert_invert", "bunny_4k_16spp", "bunny_1080p_ao64_closeup"}
+    for v in sw.values():
+        assert v["one_gpu_ms"] > 0 and v["render_only_ms"] > 0 and v["render_plus_gather_ms"] > 0 and v["n_gpus"] == nranks
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that cannot start (more RCCL ranks than GPUs on this box) ends the whole launch with a non-zero status
+    and no JSON line, instead of leaving the others waiting."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=110)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "needs %d GPUs" % n in p.stderr

@@ -172,6 +172,27 @@ def test_tile_sharding_and_deinterleave(bunny_scene, gpu_ctx, nranks, tile):
     assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full[2])
 
 
+@pytest.mark.parametrize("nranks,tile", [(3, 64), (5, 32)])
+def test_dense_deinterleave_with_an_idle_root_and_the_default_stride(bunny_scene, gpu_ctx, nranks, tile):
+    """INV_ROOT_IDLE, dense layout, rank_stride left at 0 ("back to back"): the buffers of the ranks lie one drawing
+    rank's slot count apart, rank 0's (unused) part included."""
+    import torch
+    w, h = 1000, 600
+    cam = R.camera_reference(w, h)
+    full = bunny_scene.render(cam, R.make_params(w, h))
+    prm = [R.make_params(w, h, tile=tile, rank=r, nranks=nranks, flags=R.ROOT_IDLE) for r in range(nranks)]
+    npix, _ = R.tile_layout(prm[1])
+    assert R.tile_layout(prm[0])[0] == 0 and npix > 0
+    gathered = torch.full((nranks, npix), 0x3C3C3C3C, dtype=torch.int32, device="cuda")
+    scratch = torch.empty(2, npix, dtype=torch.int32, device="cuda")
+    for r in range(1, nranks):
+        bunny_scene.render_device(cam, prm[r], scratch[0].data_ptr(), scratch[1].data_ptr(), gathered[r].data_ptr())
+    out = torch.empty(h * w, dtype=torch.int32, device="cuda")
+    gpu_ctx.deinterleave(prm[0], gathered.data_ptr(), out.data_ptr())  # rank_stride = 0
+    gpu_ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), full[2])
+
+
 _sparse_composite_single_gpu = common.sparse_composite_single_gpu
 
 

@@ -49,6 +49,34 @@ def test_noalloc_entry_point_matches_inv_render(bunny_path):
         ctx.close()
 
 
+def test_noalloc_entry_point_leaves_free_memory_as_it_is(bunny_path):
+    """A scene that inv_render has never drawn (no occlusion queue, no wide node records, no bins exist yet): the
+    first-ever occlusion draw through inv_render_noalloc alone leaves the driver's count of free device bytes
+    unchanged, and its frame equals the one a second scene gets from inv_render."""
+    ctx = R.Context(0)
+    fresh = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
+    other = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
+    try:
+        w, h = 1280, 720
+        cam, prm = R.camera_reference(w, h), R.make_params(w, h, ao_rays=32, seed=5, flags=R.LAMBERT | R.INVERT)
+        a = torch.full((3, w * h), 0x55, dtype=torch.int32, device="cuda")
+        b = torch.full((3, w * h), 0x66, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]  # hipMemGetInfo: the driver's figure, not torch's allocator
+        for _ in range(2):
+            fresh.render_noalloc(cam, prm, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before
+        other.render_device(cam, prm, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr())
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info()[0] < free_before  # the ordinary draw does allocate (queue, wide records)
+        assert np.array_equal(b.cpu().numpy(), a.cpu().numpy())
+    finally:
+        fresh.close()
+        other.close()
+        ctx.close()
+
+
 def test_noalloc_entry_point_rejects_what_needs_memory(bunny_path):
     ctx = R.Context(0)
     scene = R.Scene(ctx, R.Mesh.load_obj(bunny_path))
