@@ -43,10 +43,13 @@ def _launch_ranks():
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks from here.
 
     This runs before torch, the library or anything else that could open the GPU is imported: the parent only starts
-    N fresh interpreters of this file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, as
-    torch.distributed.run would), passes rank 0's standard output through (the one JSON line), sends the other
-    ranks' standard output to standard error, and exits with the worst status.  A rank that fails takes the others
-    down with it (they would wait in a collective for ever).  Returns None when there is nothing to launch."""
+    other processes and never touches a GPU itself.  By default it hands the job to torch's own launcher
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`),
+    which keeps the rendezvous store and ends every worker when one fails; INV_BENCH_LAUNCHER=spawn starts N
+    interpreters of this file directly instead (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, each
+    in a session of its own; a rank that fails takes the others down after five seconds).  Either way only the JSON
+    line of rank 0 reaches standard output (what libraries print there goes to standard error) and the exit status
+    is the worst of the ranks'.  Returns None when there is nothing to launch."""
     if "WORLD_SIZE" in os.environ:
         return None
     ap = argparse.ArgumentParser(add_help=False)
@@ -57,16 +60,44 @@ def _launch_ranks():
     import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    variant = os.environ.get("INV_BENCH_LAUNCHER", "torchrun")
+
+    def forward(stream):  # the JSON line to standard output, anything else a library printed there to standard error
+        for raw in stream:
+            line = raw.decode("utf-8", "replace")
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+
+    if variant == "torchrun":
+        # torch's own launcher does the rest: one worker per rank, the rendezvous store in the launcher, and the end of
+        # every worker when one of them fails
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+        pump = threading.Thread(target=forward, args=(p.stdout,), daemon=True)
+        pump.start()
+        try:
+            rc = p.wait()
+        except KeyboardInterrupt:
+            p.send_signal(signal.SIGINT)
+            rc = p.wait()
+        pump.join(timeout=10)
+        return rc if rc >= 0 else 128 - rc
     procs = []
     for r in range(known.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(known.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), INV_BENCH_LAUNCHED_BY=str(os.getpid()))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+        renv = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(known.gpus), MASTER_ADDR="127.0.0.1",
+                    MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=renv,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      start_new_session=True))
+    pump = threading.Thread(target=forward, args=(procs[0].stdout,), daemon=True)
+    pump.start()
     worst, failed_at = 0, None
     try:
         while any(p.poll() is None for p in procs):
@@ -93,6 +124,7 @@ def _launch_ranks():
             rc = p.wait()
         if rc != 0:
             worst = max(worst, rc if rc > 0 else 128 - rc)
+    pump.join(timeout=10)
     return worst
 
 
@@ -250,7 +282,25 @@ def main():
                          "from close by) that follow the timed region and show where sharding pays")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on one GPU (ranks share cuda:0, gather through host memory)")
+    ap.add_argument("--watchdog-seconds", type=int, default=1500,
+                    help="a rank still running after this long writes every thread's Python stack to standard error and "
+                         "exits with a failure, so that a collective that never completes ends the run with a message "
+                         "instead of hanging it (0: off)")
     args = ap.parse_args()
+    if args.watchdog_seconds > 0:
+        import faulthandler
+        import threading
+
+        def give_up():
+            sys.stderr.write("bench.py: rank %s still running after %d s; stacks of its threads:\n"
+                             % (os.environ.get("RANK", "0"), args.watchdog_seconds))
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+            os._exit(3)
+
+        watchdog = threading.Timer(args.watchdog_seconds, give_up)
+        watchdog.daemon = True
+        watchdog.start()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

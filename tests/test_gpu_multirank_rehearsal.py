@@ -71,22 +71,30 @@ def test_bench_with_the_librarys_own_exchange(nranks, extra):
     assert "inv_comm_gather" in r["config"]["parallelism"]
 
 
-@pytest.mark.gpu
-@pytest.mark.timeout(240)
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_bench_starts_its_own_ranks(nranks):
-    """`python bench.py --gpus N` without torch.distributed.run and without WORLD_SIZE: the parent starts the N ranks
-    itself (before anything opens the GPU), rank 0's line comes out once, and it carries the per-workload phase times
-    the scaling curve is read from."""
+def _clean_env(**extra):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("nranks,launcher,extra", [(2, "torchrun", ()), (3, "spawn", ("--no-extra-workloads",))])
+def test_bench_starts_its_own_ranks(nranks, launcher, extra):
+    """`python bench.py --gpus N` without torch.distributed.run and without WORLD_SIZE: the parent starts the N ranks
+    itself (before anything opens the GPU; through torch's launcher, or directly), exactly one line comes out, and it
+    carries the per-workload phase times the scaling curve is read from."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--backend", "gloo", "--steps", "3",
-           "--warmup", "1", "--frames-per-step", "2"]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=230)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+           "--warmup", "1", "--frames-per-step", "2", "--watchdog-seconds", "100", *extra]
+    p = subprocess.run(cmd, cwd=ROOT, env=_clean_env(INV_BENCH_LAUNCHER=launcher), capture_output=True, text=True, timeout=190)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines) == 1, p.stdout[-2000:]  # what gloo prints on standard output was sent to standard error
     r = json.loads(lines[0])
     assert r["n_gpus"] == nranks and r["steps"] == 3 and r["value"] > 0
+    if extra:
+        assert "scaling_workloads" not in r
+        return
     sw = r["scaling_workloads"]
     assert set(sw) == {"bunny_1080p_primary_lambert_invert", "bunny_4k_16spp", "bunny_1080p_ao64_closeup"}
     for v in sw.values():
@@ -98,11 +106,10 @@ def test_bench_starts_its_own_ranks(nranks):
 def test_bench_launcher_reports_a_failing_rank():
     """A rank that cannot start (more RCCL ranks than GPUs on this box) ends the whole launch with a non-zero status
     and no JSON line, instead of leaving the others waiting."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     import torch
     n = torch.cuda.device_count() + 1
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=110)
+                       cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=110)
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "needs %d GPUs" % n in p.stderr
