@@ -5,6 +5,7 @@ the pins are (a) facts about res/bunny.obj and the reference's literals that can
 derived independently of the oracle's code, and (b) this repo's committed goldens.
 """
 import hashlib
+import sys
 
 import numpy as np
 import pytest
@@ -316,3 +317,28 @@ def test_lambert_and_invert_against_numpy(oracle, bunny_mesh):
         assert (color[..., 3] == 255).all()
         bg = 255 if flags & 2 else 0
         assert (color[..., :3][op == 0xFFFFFFFF] == bg).all()
+
+
+@pytest.mark.parametrize("size,golden", [("512x512", "bunny_512"), ("1920x1080", "bunny_1080_rect")])
+def test_vulkan_raster_rules_bound_the_unpinned_part(size, golden):
+    """The goldens are ray casts through pixel centres with inclusive edges and unsnapped positions; what
+    vkCmdDrawIndexed (src/invert.cpp:828; state :1331-1337, :1375-1385) draws is decided by a rasteriser with the
+    top-left fill rule and positions snapped to subPixelPrecisionBits.  The numpy rasteriser under those rules against
+    the goldens, per pixel: the top-left rule alone moves nothing (no pixel centre lies exactly on an edge); snapping
+    to 8 sub-pixel bits hands 5 of 5 651 / 13 of 25 139 covered pixels to a neighbouring triangle and changes no
+    pixel between hit and miss; the 4 bits the specification allows as a minimum move 138 / 275 (5 / 6 of them between
+    hit and miss).  The counts and the pixels are pinned in pins.json (tests/golden/make_raster_bounds.py)."""
+    sys.path.insert(0, common.GOLDEN)
+    import make_raster_bounds as B
+    pinned = common.pins()["vulkan_raster_bounds"][size]
+    assert set(pinned) == set(B.VARIANTS)
+    for variant in B.VARIANTS:
+        got = B.bounds(size, golden, variant)
+        assert got == pinned[variant], variant
+    n = pinned["inclusive_edges_unsnapped"]["golden_covered"]
+    assert pinned["top_left_unsnapped"]["primitive_id_differs"] == pinned["inclusive_edges_unsnapped"]["primitive_id_differs"] <= 1
+    eight, four = pinned["top_left_8_subpixel_bits"], pinned["top_left_4_subpixel_bits"]
+    assert eight["primitive_id_differs"] <= 0.001 * n and eight["hit_in_golden_only"] == eight["hit_in_variant_only"] == 0
+    assert four["primitive_id_differs"] <= 0.03 * n and four["hit_in_golden_only"] + four["hit_in_variant_only"] <= 6
+    # a neighbour's depth at the same pixel: the snapped variants stay within 2^-13 of the goldens where the ids agree
+    assert eight["max_depth_difference_in_2^-24"] < 1024 and four["max_depth_difference_in_2^-24"] < 4096
