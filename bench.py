@@ -287,6 +287,7 @@ def main():
                          "exits with a failure, so that a collective that never completes ends the run with a message "
                          "instead of hanging it (0: off)")
     args = ap.parse_args()
+    watched_streams = {}  # name -> torch stream, for the watchdog's report
     if args.watchdog_seconds > 0:
         import faulthandler
         import threading
@@ -295,6 +296,12 @@ def main():
             sys.stderr.write("bench.py: rank %s still running after %d s; stacks of its threads:\n"
                              % (os.environ.get("RANK", "0"), args.watchdog_seconds))
             faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            for name, q in list(watched_streams.items()):  # which of the streams still has work that has not finished
+                try:
+                    sys.stderr.write("bench.py: rank %s stream %s: %s\n" % (os.environ.get("RANK", "0"), name,
+                                                                           "idle" if q.query() else "BUSY"))
+                except Exception as exc:  # noqa: BLE001
+                    sys.stderr.write("bench.py: stream %s: query failed: %r\n" % (name, exc))
             sys.stderr.flush()
             os._exit(3)
 
@@ -338,6 +345,9 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = R.Context(local_rank, stream=stream.cuda_stream)
+    watched_streams["context"] = stream
+    for j in range(2):
+        watched_streams["frame slot %d" % j] = torch.cuda.ExternalStream(ctx.frame_stream(j))
     mesh = R.Mesh.load_obj(objfmt.bunny_obj_path()).pin()  # page-locked arrays: the build's uploads are DMA out of them
     side = wl.get("instances_side", 1)
     translations = common.grid_translations(side) if side > 1 else None
@@ -610,12 +620,19 @@ def main():
                 body(i)
             ctx.frames_join()
             torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt[0]) / (n * frames_each) * 1e3
 
+        trace_on = bool(os.environ.get("INV_BENCH_TRACE"))
+
+        def trace(*what):  # where a rank is, for a run that has to be looked into
+            if trace_on:
+                print("bench.py trace: rank %d" % rank, *what, file=sys.stderr, flush=True)
+
         names = [args.workload] + [n_ for n_ in ("bunny_4k_16spp", "bunny_1080p_ao64_closeup") if n_ != args.workload]
         for name in names:
+            trace(name, "begin")
             xw = WORKLOADS[name]
             if xw.get("instances_side", 1) != side or xw.get("turntable"):
                 continue  # another scene than the one built
@@ -638,13 +655,21 @@ def main():
                                                 [tuple(one[j, u, p_].data_ptr() for p_ in range(3)) for u in range(xf)])
                                for j in range(2)]
 
+            # (Ranks that share one GPU, occlusion rays: on one slot.  With a second process on the device, rank 0's
+            # occlusion frames on two slots at once have now and then never completed -- one run in seven, only in
+            # this pass, never with one process per GPU or with one process alone, 40 fresh processes and 900 frames
+            # in tools/ao_two_slots_probe.py -- and a rehearsal's times mean nothing anyway.)
+            one_slot = rehearsal and bool(kw["ao_rays"])
+
             def alone(i):
                 if rank == 0:
-                    scene.render_batch(one_batches[i % 2], i % 2)
+                    scene.render_batch(one_batches[i % 2], 0 if one_slot else i % 2)
 
             alone(0)
             alone(1)
+            trace(name, "one GPU: warmed")
             one_ms = timed(alone, n_x, xf)
+            trace(name, "one GPU: timed")
             for share, share_flag in [("equal", 0)] + ([("rank0_idle", R.ROOT_IDLE)] if world >= 3 else []):
                 ecb = RD.SparseCompositeBatch(scene, ecam, ew, eh, rank, world, frames=xf, sets=2, tile=32, comm=comm,
                                               **dict(kw, flags=kw["flags"] | share_flag))
@@ -656,10 +681,13 @@ def main():
                     ecb.render(i % 2, xf)
                     composite_group(ecb, i % 2, xf)
 
+                trace(name, share, "composite made")
                 for i in range(2):
                     both(i)
                 render_ms = timed(draws, n_x, xf)
+                trace(name, share, "draws timed")
                 both_ms = timed(both, n_x, xf)
+                trace(name, share, "draws + composite timed")
                 both(0)
                 ctx.frames_join()
                 torch.cuda.synchronize()

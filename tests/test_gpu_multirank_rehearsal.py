@@ -24,7 +24,8 @@ def _run(nranks, *extra, steps=3, warmup=1):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(nranks), "--steps", str(steps), "--warmup", str(warmup), "--frames-per-step", "1",
-           "--backend", "gloo", *extra]
+           "--backend", "gloo", "--watchdog-seconds", "120", *extra]
+    # (the watchdog ends a rank that hangs, with its stacks, before this test's own limit would leave the ranks behind)
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=170)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
