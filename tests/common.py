@@ -79,10 +79,25 @@ def flatten_instances(xyzw, idx, translations):
     return out_v, out_i
 
 
-def pulled_back_camera(cam, distance, height=0.11):
-    """The reference camera moved back along +z so that a grid of instances fits the view (same roll and lens)."""
+def pulled_back_camera(cam, distance, height=0.11, far=None):
+    """The reference camera moved back along +z so that a grid of instances fits the view (same roll and lens).
+
+    `far`: another far plane than the reference's 10 (src/invert.cpp:639) for grids that lie beyond it: the two terms
+    of glm::perspective (zero-to-one depth) that hold it, in float32: P22 = far / (near - far), P32 = -(far near) /
+    (far - near), near 0.1 as in the reference."""
     cam.view[12], cam.view[13], cam.view[14] = 0.0, float(np.float32(height)), float(-np.float32(distance))
+    if far is not None:
+        near, far = np.float32(0.1), np.float32(far)
+        cam.proj[10] = float(np.float32(far / np.float32(near - far)))
+        cam.proj[14] = float(np.float32(-np.float32(far * near) / np.float32(far - near)))
     return cam
+
+
+def grid_camera(cam, side):
+    """The camera the benchmarks and tests look at a side x side grid of instances with: pulled back by 0.27 per
+    instance of the grid's side, and with the far plane at 100 once that is beyond the reference's far plane."""
+    distance = 0.27 * side
+    return pulled_back_camera(cam, distance, far=100.0 if distance + 0.5 > 10.0 else None)
 
 
 def oracle_params(oracle, prm):

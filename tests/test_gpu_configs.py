@@ -3,7 +3,8 @@
   config 3  bunny, 3840 x 2160, 16 jittered samples per pixel, seed 0: the whole frame, and the same frame as the
             shards of 2 / 4 / 8 ranks put together again on this GPU (dense and sparse layouts)
   config 4  32 x 32 = 1024 bunny instances flattened into one LBVH (5 087 232 triangles), 1080p: the LBVH against
-            the sequential build, the frame against the oracle
+            the sequential build, the frame against the oracle; and 118 x 118 = 13 924 instances (69 174 432
+            triangles, the scale the configuration states) the same way
   config 5  bunny, 1080p, 64 occlusion rays per hit pixel: as the shards of 8 ranks, and from close by (318 k hit
             pixels, 20 M occlusion rays)
 
@@ -101,6 +102,42 @@ def test_config4_1024_instances(oracle, gpu_ctx, bunny_path, bunny_mesh):
     finally:
         scene.close()
         gpu_ctx.trim()  # 0.6 GB of build scratch
+
+
+@pytest.mark.timeout(900)
+def test_config4_at_the_stated_scale_of_70_million_triangles(oracle, gpu_ctx, bunny_path, bunny_mesh):
+    """BASELINE.json's fourth configuration says "~70M tris"; with the 4 968-triangle mesh of res/ that is 118 x 118 =
+    13 924 instances, 69 174 432 triangles (4.4 GB of node records: offsets beyond 32 bits; more sort tiles than one
+    workgroup can add up, so the scan's second level runs as a kernel of its own).  The LBVH against the sequential
+    build, the frame against the oracle, and the tile path against both."""
+    side = 118
+    tr = common.grid_translations(side)
+    scene = R.Scene(gpu_ctx, R.Mesh.load_obj(bunny_path), translations=tr)
+    try:
+        ntri, nnodes, _ = scene.counts()
+        assert (ntri, nnodes) == (13924 * 4968, 13924 * 4968 - 1) and ntri == 69174432
+        fx, fi = common.flatten_instances(*bunny_mesh, tr)
+        common.check_lbvh(oracle, scene, fx, fi)
+        w, h = 1920, 1080
+        cam = common.grid_camera(R.camera_reference(w, h), side)  # 31.9 away, far plane at 100
+        assert cam.proj[10] != R.camera_reference(w, h).proj[10]
+        ocam = oracle.Camera.from_buffer_copy(bytes(cam))
+        prm = R.make_params(w, h, flags=FLAGS)
+        assert scene.draw_path(cam, prm) == R.api.PATH_SCATTER  # some seventy triangles per pixel
+        got = scene.render(cam, prm)
+        want = oracle.render_bvh(fx, fi, ocam, common.oracle_params(oracle, prm))
+        del fx, fi
+        common.assert_frames_equal(got, want, "config 4 at 69 M triangles")
+        hits = got[2] != 0xFFFFFFFF
+        assert hits.sum() > 300000 and len(np.unique(got[2][hits] // 4968)) == 13924  # every instance is seen
+        # through the LBVH: a binning pass and 8x8 tiles in batches; sample 0 alone decides depth and primitive id
+        prm2 = R.make_params(w, h, spp=2, seed=1, flags=FLAGS)
+        assert scene.draw_path(cam, prm2) == R.api.PATH_TILES_BATCHED | R.api.PATH_BINNED
+        got2 = scene.render(cam, prm2)
+        assert np.array_equal(got2[2], want[2]) and np.array_equal(got2[1].view(np.uint32), want[1].view(np.uint32))
+    finally:
+        scene.close()
+        gpu_ctx.trim()  # some 4 GB of build scratch
 
 
 def test_config5_ao64_as_shards_of_8_ranks(oracle, bunny_scene, gpu_ctx, bunny_mesh):

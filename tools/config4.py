@@ -46,10 +46,15 @@ def main():
     print("build: %d triangles, %.1f MB scene; host wall including upload and the final sync: first %.2f ms, then "
           "median %.2f ms, min %.2f ms over %d builds" % (ntri, nbytes / 1e6, times[0], float(np.median(times[1:])),
                                                           min(times[1:]), len(times) - 1))
-    cam = common.pulled_back_camera(R.camera_reference(w, h), 0.27 * a.side)
+    cam = common.grid_camera(R.camera_reference(w, h), a.side)
     buf = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
-    for name, flags in (("tile kernel (auto)", 0), ("lane traversal", R.LANE_TRAVERSAL)):
-        prm = R.make_params(w, h, flags=R.LAMBERT | R.INVERT | flags)
+    rows = [("auto (one sample)", 0, 1), ("auto (two samples: the tile kernel)", 0, 2)]
+    if a.side <= 40:
+        rows.append(("lane traversal", R.LANE_TRAVERSAL, 1))
+    for name, flags, spp in rows:
+        prm = R.make_params(w, h, spp=spp, seed=1, flags=R.LAMBERT | R.INVERT | flags)
+        path = scene.draw_path(cam, prm)
+        name = "%s [path %d%s]" % (name, path & 15, ", binned" if path & R.api.PATH_BINNED else "")
         for _ in range(2):
             scene.render_device(cam, prm, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr())
         stream.synchronize()
@@ -61,7 +66,7 @@ def main():
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 5
         hits = int((buf[2] != -1).sum())
-        print("%-20s %.3f ms per frame, %.1f Mrays/s, %d hit pixels" % (name, ms, w * h / ms / 1e3, hits))
+        print("%-48s %.3f ms per frame, %.1f Mrays/s, %d hit pixels" % (name, ms, w * h / ms / 1e3, hits))
     if a.check:
         from oracle import oracle as O
         xyzw, idx = O.load_obj(objfmt.bunny_obj_path())
