@@ -587,7 +587,11 @@ void lbvh_build(const std::vector<Tri>& tris, Lbvh& b) {
         b.lo = {std::min(b.lo.x, lo[k].x), std::min(b.lo.y, lo[k].y), std::min(b.lo.z, lo[k].z)};
         b.hi = {std::max(b.hi.x, hi[k].x), std::max(b.hi.y, hi[k].y), std::max(b.hi.z, hi[k].z)};
     }
+    // One grid step for all three axes (the largest extent): cubic cells, whatever the shape of the scene.  (With a
+    // step per axis a flat scene -- a grid of instances in a plane -- gets cells that are thin slabs, and consecutive
+    // keys then walk around an instance instead of across a patch of its surface.)
     V3 ext = sub(b.hi, b.lo);
+    ext.x = ext.y = ext.z = std::max(ext.x, std::max(ext.y, ext.z));
     std::vector<std::pair<uint64_t, uint32_t>> keys(n);
     for (uint32_t k = 0; k < n; k++) {
         float cx = (lo[k].x + hi[k].x) * 0.5f, cy = (lo[k].y + hi[k].y) * 0.5f, cz = (lo[k].z + hi[k].z) * 0.5f;

@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, Me
     }
     float lo[3], hi[3];
     tri_box(ra, rb, rc, lo, hi);
-    float ex = bbox[3] - bbox[0], ey = bbox[4] - bbox[1], ez = bbox[5] - bbox[2];
+    // one grid step for all three axes (the largest extent): cubic cells, whatever the shape of the scene -- with a
+    // step per axis a flat scene (a grid of instances in a plane) gets cells that are thin slabs, and consecutive keys
+    // then walk around an instance instead of across a patch of its surface
+    float ex = fmaxf(bbox[3] - bbox[0], fmaxf(bbox[4] - bbox[1], bbox[5] - bbox[2])), ey = ex, ez = ex;
     float cx = (lo[0] + hi[0]) * 0.5f, cy = (lo[1] + hi[1]) * 0.5f, cz = (lo[2] + hi[2]) * 0.5f;
     keys[i] = (expand21(grid21(cx, bbox[0], ex)) << 2) | (expand21(grid21(cy, bbox[1], ey)) << 1) |
               expand21(grid21(cz, bbox[2], ez));
