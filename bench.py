@@ -589,6 +589,25 @@ def main():
         torch.cuda.synchronize()
         alone_ms = a0.elapsed_time(a1) / len(submissions)
 
+    # Frames drawn one lane per triangle never touch the LBVH: the same frames through it (the tile kernel behind a
+    # binning pass, INV_TILE_TRAVERSAL), timed the same way on the same slots, for comparison
+    lbvh_path_ms = None
+    if world == 1 and slots_used and not args.no_extra_passes and not turntable:
+        path_now = scene.draw_path(cam, prm)
+        if (path_now & 15) == R.api.PATH_SCATTER:
+            tprm = R.make_params(w, h, spp=spp, flags=flags | R.TILE_TRAVERSAL, ao_rays=ao_rays)
+            n_t = min(len(submissions), 8)
+            tsubs = [(j, n, scene.make_batch([cam] * n, [tprm] * n, [slot_ptr[(k * fpl + u) % len(slot_ptr)] for u in range(n)]))
+                     for k, (j, n, _) in enumerate(submissions[:n_t])]
+            run(tsubs)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            run(tsubs)
+            torch.cuda.synchronize()
+            lbvh_path_ms = (time.perf_counter() - ts) / sum(n for _, n, _ in tsubs) * 1e3
+            run(submissions[-min(len(submissions), fif * rotate):])  # the attachments hold the timed path's frames again
+            torch.cuda.synchronize()
+
     # The same job through one group of sets per slot only (fif * fpl sets: 299 MB for the headline, less than the
     # Infinity Cache could hold if the stores were kept there): the stores are non-temporal, so this should make no
     # difference; reported to show that the timed region does not lean on that cache.
@@ -773,6 +792,9 @@ def main():
                        "draw_path": ("16x16 blocks, %d frames per launch" % fpl if kernel_name.startswith("k_render_tile_batch")
                                      else path_names[path & 15] + (" after a binning pass" if path & R.api.PATH_BINNED else "")),
                        "bytes_read_per_frame": read_bytes,
+                       # ms per frame of the same frames drawn through the LBVH (tile kernel behind a binning pass) when the
+                       # timed frames were drawn one lane per triangle, which never touches the tree; else null
+                       "lbvh_path_ms": lbvh_path_ms,
                        # host wall of the scene build (upload from a pinned mesh, assembly, LBVH): the first build (with allocations)
                        # and the median of the five that follow
                        "build_ms": [build_ms[0], float(np.median(build_ms[1:]))], "mesh_pinned": True, "tile": tile, "frames_in_flight": fif, "frames_per_launch": fpl,

@@ -53,6 +53,7 @@ enum {
     INV_LANE_TRAVERSAL = 16u, /* one lane per ray with a stack in LDS instead of the tile kernel's candidate lists */
     INV_SPARSE = 32u,     /* with nranks > 1: deal out only the tiles that can contain hits (see inv_sparse_layout) */
     INV_ROOT_IDLE = 128u, /* with nranks >= 3: rank 0 takes no tiles (it alone writes the background of a sparse composite and receives everyone's tiles); tile id belongs to rank 1 + id % (nranks - 1).  Every rank of a frame passes the same flag */
+    INV_TILE_TRAVERSAL = 256u, /* draw through the LBVH with the tile kernel even where triangles are so much smaller than a pixel that the frame would be drawn one lane per triangle (which needs 8 bytes per pixel of visibility buffer and never touches the tree): same pixels, for callers that want the tree walked and for measuring one path against the other */
     INV_BLOCKS = 64u,     /* trace 16x16 pixel blocks with a wave per quadrant, as inv_render_batch does, instead of 8x8 tiles whose waves share the candidates: less arithmetic, longer for a draw on its own, and slow where a block meets hundreds of triangles (its pixels then go through the per-lane traversal) */
 };
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # INVERT_HIP_LIB names another build of the same library (tuning experiments); the default is the in-tree build
 LIB_PATH = os.environ.get("INVERT_HIP_LIB") or os.path.join(_HERE, "libinvert_hip.so")
 
-LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL, SPARSE, BLOCKS, ROOT_IDLE = 1, 2, 4, 8, 16, 32, 64, 128
+LAMBERT, INVERT, RGBA, BRUTE_FORCE, LANE_TRAVERSAL, SPARSE, BLOCKS, ROOT_IDLE, TILE_TRAVERSAL = 1, 2, 4, 8, 16, 32, 64, 128, 256
 PATH_BRUTE, PATH_LANES, PATH_BLOCKS, PATH_TILES, PATH_TILES_BATCHED, PATH_SCATTER, PATH_BINNED = 0, 1, 2, 3, 4, 5, 16
 MAX_FRAMES_IN_FLIGHT = 4  # INV_MAX_FRAMES_IN_FLIGHT
 CONTEXT_STREAM = 0xFFFFFFFF  # INV_CONTEXT_STREAM

@@ -600,13 +600,28 @@ int inv_scene_read_lbvh(inv_scene* scene, uint64_t* morton, uint32_t* order, uin
     size_t n = d.ntri;
     if (morton) HIP_TRY(hipMemcpy(morton, d.morton, n * 8, hipMemcpyDeviceToHost));
     if (order) HIP_TRY(hipMemcpy(order, d.order, n * 4, hipMemcpyDeviceToHost));
-    if (child) HIP_TRY(hipMemcpy(child, d.child, (n - 1) * 8, hipMemcpyDeviceToHost));
-    if (parent) HIP_TRY(hipMemcpy(parent, d.parent, (n - 1) * 4, hipMemcpyDeviceToHost));
-    if (leaf_parent) HIP_TRY(hipMemcpy(leaf_parent, d.leaf_parent, n * 4, hipMemcpyDeviceToHost));
-    if (box) {
+    if (child || parent || leaf_parent || box) try {
+        // the node records are all the scene keeps of the hierarchy: child references in words 12 and 13 of each, and
+        // every node but the root is somebody's child
         std::vector<float> nodes((n - 1) * 16);
         HIP_TRY(hipMemcpy(nodes.data(), d.nodes, (n - 1) * 64, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i + 1 < n; i++) std::memcpy(box + 12 * i, nodes.data() + 16 * i, 48);
+        if (parent) parent[0] = 0xFFFFFFFFu;
+        for (size_t i = 0; i + 1 < n; i++) {
+            if (box) std::memcpy(box + 12 * i, nodes.data() + 16 * i, 48);
+            uint32_t c[2];
+            std::memcpy(c, nodes.data() + 16 * i + 12, 8);
+            if (child) child[2 * i] = c[0], child[2 * i + 1] = c[1];
+            for (int k = 0; k < 2; k++) {
+                const uint32_t at = c[k] & 0x7FFFFFFFu;
+                if (c[k] >> 31) {
+                    if (leaf_parent && at < n) leaf_parent[at] = (uint32_t)i;
+                } else if (parent && at + 1 < n) {
+                    parent[at] = (uint32_t)i;
+                }
+            }
+        }
+    } catch (...) {
+        return fail(INV_ERR_NOMEM, "inv_scene_read_lbvh: out of host memory");
     }
     return INV_OK;
 }
@@ -663,7 +678,7 @@ int prepare_frame(const inv_scene* scene, const inv_camera* cam, const inv_param
     {
         // Bits above the INV_* flags switch parts of the kernels off for timing experiments (tools/phase_timing.py,
         // tools/tile_stats.py) and make the images wrong: they are refused unless INV_TIMING_SWITCHES is set.
-        constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE | INV_BLOCKS | INV_ROOT_IDLE;
+        constexpr uint32_t known = INV_LAMBERT | INV_INVERT | INV_RGBA | INV_BRUTE_FORCE | INV_LANE_TRAVERSAL | INV_SPARSE | INV_BLOCKS | INV_ROOT_IDLE | INV_TILE_TRAVERSAL;
 #ifdef INV_TIMING_BUILD
         static const bool allow = std::getenv("INV_TIMING_SWITCHES") != nullptr;
 #else

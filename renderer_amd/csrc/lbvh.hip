@@ -306,19 +306,28 @@ constexpr uint32_t kRunMax = 48;
 __global__ __launch_bounds__(256) void k_sort_runs(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t n,
                                                    int shift, uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                    uint32_t* __restrict__ too_long) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    // the workgroup's 256 keys and kRunMax on either side, in LDS: a key's looks at its neighbours are dependent steps,
+    // a dozen or more of them where cells hold several triangles
+    __shared__ uint64_t s_k[256 + 2 * kRunMax];
+    const uint32_t base = blockIdx.x * 256u, t = threadIdx.x, i = base + t;
+    for (uint32_t j = t; j < 256u + 2u * kRunMax; j += 256u) {
+        const int64_t g = (int64_t)base - (int64_t)kRunMax + j;
+        s_k[j] = g >= 0 && g < (int64_t)n ? kin[g] : 0ull; // (places outside the array are never looked at)
+    }
+    __syncthreads();
     if (i >= n) return;
-    const uint64_t k = kin[i], hi = k >> shift;
+    const uint32_t p = t + kRunMax; // key i sits at s_k[p]
+    const uint64_t k = s_k[p], hi = k >> shift;
     uint32_t a = i, b = i + 1u;
-    while (a > 0u && i - a < kRunMax && (kin[a - 1u] >> shift) == hi) a--;
-    while (b < n && b - i <= kRunMax && (kin[b] >> shift) == hi) b++; // (b - i counts key i itself)
+    while (a > 0u && i - a < kRunMax && (s_k[p - (i - a) - 1u] >> shift) == hi) a--;
+    while (b < n && b - i <= kRunMax && (s_k[p + (b - i)] >> shift) == hi) b++; // (b - i counts key i itself)
     uint32_t at = i;
     if (b - a > kRunMax) {
         *too_long = 1u; // (every thread that comes here writes the same value)
     } else if (b - a > 1u) {
         uint32_t before = 0;
         for (uint32_t j = a; j < b; j++) {
-            const uint64_t kj = kin[j];
+            const uint64_t kj = s_k[p + j - i];
             before += (kj < k || (kj == k && j < i)) ? 1u : 0u;
         }
         at = a + before;
@@ -440,6 +449,7 @@ __device__ __forceinline__ void emit_fine(bool finished, uint32_t c0, uint2 leav
 // are already complete (leaves, and nodes finished inside a chunk) and puts it in a slot to be climbed from if both
 // are.
 constexpr uint32_t kChunk = 512; // (1024 leaves per workgroup: 12 % slower at five million triangles)
+static_assert(kChunk == 512, "k_build_chunks packs positions within a chunk into nine bits");
 constexpr uint32_t kOpen = 0xFFFFFFFFu;
 
 // The slot of a node that waits to be climbed from: two per unit of leaves (a chunk, a span), the one for the node
@@ -572,6 +582,395 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
     __syncthreads();
     if (t < 2u && !s_taken[t]) slots[2 * (size_t)(2u * chunk + t)] = make_uint4(0u, 0u, 0u, 0u);
     if (i == 0u && height != kOpen) *root_done = 1u; // one chunk holds it all
+}
+
+// ------------------------------------------------------------------------------------------
+// 5b. hierarchy and boxes of a chunk in one pass, bottom-up (C. Apetrei, "Fast and Simple Agglomerative LBVH
+//     Construction", 2014), in LDS.  A node over the sorted leaves [l, r] is the child of the node that also holds
+//     whichever neighbour, l - 1 or r + 1, shares the longer key prefix with it: with delta(p) the common prefix of
+//     the keys at p and p + 1 (index bits appended, so no two boundaries of one node tie), it is the left child of the
+//     node split at r if delta(r) > delta(l - 1), else the right child of the node split at l - 1.  Two children meet at
+//     their parent's split: the first to arrive leaves the far end of its range there and stops, the second merges
+//     and goes on.  No node searches for anything.  In T. Karras's numbering (which the rest of the build and the
+//     sequential restatement use) a left child is named after the last leaf of its range and a right child after the
+//     first, so a node learns its own name when it learns which side its parent is on, and the children of a node
+//     split at g are g and g + 1.
+//     What a chunk cannot finish are the nodes whose leaves reach into another chunk.  It hands up its "tops": the
+//     subtrees (or single leaves) it made whose sibling lies elsewhere, a dozen or so, in leaf order, each with its box,
+//     its leaves, its height and the prefixes at its two ends.  k_build_level does the same merging over the tops of
+//     32 units at a time, again in LDS, and hands up its own tops, until one workgroup holds what is left: three
+//     further launches for five million triangles, no node ever searching or waiting for anything in memory.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMerged = 0xFFFFFFFFu;
+constexpr uint32_t kTopCap = 64;       // tops a unit may hand up (more: the build starts again the other way)
+constexpr uint32_t kLevelUnits = 32;   // units whose tops one workgroup of k_build_level merges
+constexpr uint32_t kLevelItems = 768;  // tops it can hold (32 units hand up some 400; two such workgroups share a CU's LDS)
+constexpr uint32_t kLevelThreads = 1024; // a lane per top: a lane with two to carry would start the second when the first has stopped
+constexpr uint32_t kLevelFine = 256;   // records of the fine cut it collects before it writes them out
+// A top: (box lo xyz, first leaf) (box hi xyz, last leaf) (prefix at the lower end + 1 | prefix at the upper end + 1 << 8
+// | height << 16, -, -, -)
+
+__device__ __forceinline__ int key_delta(uint64_t a, uint64_t b, uint32_t i, uint32_t j) {
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)(i ^ j));
+}
+
+__global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restrict__ T0, MeshSource mesh,
+                                                         const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ slot_of, float4* __restrict__ TA,
+                                                         float4* __restrict__ TB, float4* __restrict__ TC,
+                                                         uint32_t n, float* __restrict__ union_box, float* __restrict__ nodes,
+                                                         float4* __restrict__ tops, uint32_t* __restrict__ top_counts,
+                                                         uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
+                                                         uint32_t* __restrict__ finished_count, float* __restrict__ fine,
+                                                         uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
+    __shared__ float s_leaf[6][kChunk];   // boxes of the chunk's leaves
+    __shared__ float s_box[6][kChunk];    // boxes of the nodes made here, by the node's name
+    __shared__ uint64_t s_key[kChunk + 2]; // keys of the chunk and of one leaf on either side
+    __shared__ int s_delta[kChunk + 1];   // [p + 1]: common prefix of the keys at p and p + 1, p = -1 .. kChunk - 1; -1: no such leaf
+    __shared__ uint32_t s_flag[kChunk];   // per split g (between g and g + 1): 0, or the first child's far end + 1, or kMerged
+    __shared__ uint32_t s_info[kChunk];   // per node made here, by name: 1 << 31 | r << 18 | l << 9 | split
+    __shared__ uint32_t s_height[kChunk];
+    __shared__ uint32_t s_wcount[kChunk / 64], s_wmade[kChunk / 64];
+    const uint32_t chunk = blockIdx.x, t = threadIdx.x, base = chunk * kChunk, i = base + t;
+    const uint32_t count = min(kChunk, n - base); // leaves of this chunk
+    const uint32_t src = i < n ? order[i] : 0u;
+    s_key[t + 1] = i < n ? keys[i] : 0ull;
+    if (t == 0) s_key[0] = base ? keys[base - 1] : 0ull;
+    if (t == 1) s_key[kChunk + 1] = base + kChunk < n ? keys[base + kChunk] : 0ull;
+    float bx[6] = {0, 0, 0, 0, 0, 0};
+    if (i < n) {
+        // the gather into sorted order happens here, on the way (see k_refit_chunks)
+        float4 a, b, c;
+        if (mesh.xyzw) { // (the same for every lane)
+            assemble_record(mesh, src, a, b, c);
+        } else {
+            const float4* rec = T0 + 3 * (size_t)src;
+            a = rec[0], b = rec[1], c = rec[2];
+        }
+        TA[i] = a, TB[i] = b, TC[i] = c;
+        if (slot_of) slot_of[src] = i;
+        float lo[3], hi[3];
+        tri_box(a, b, c, lo, hi);
+#pragma unroll
+        for (int a = 0; a < 3; a++) s_leaf[a][t] = bx[a] = lo[a], s_leaf[3 + a][t] = bx[3 + a] = hi[a];
+    }
+    s_flag[t] = 0u, s_info[t] = 0u, s_height[t] = 0u;
+    __syncthreads();
+    {
+        // boundary between local positions t and t + 1 (and, by lane 0, between -1 and 0)
+        const bool have = i + 1u < n;
+        s_delta[t + 1] = have ? key_delta(s_key[t + 1], s_key[t + 2], i, i + 1u) : -1;
+        if (t == 0) s_delta[0] = base ? key_delta(s_key[0], s_key[1], base - 1u, base) : -1;
+    }
+    __syncthreads();
+    uint32_t l = t, r = t, h = 0;
+    int exit_gp = -2; // the split this lane's subtree waits at; -1 or kChunk - 1: a chunk boundary; -2: no subtree (or the root)
+    {
+        uint32_t split = 0;
+        bool alive = t < count;
+        while (alive) {
+            const int dl = s_delta[l], dr = s_delta[r + 1];
+            const bool whole = dl < 0 && dr < 0; // the root, all in this chunk
+            const bool right = dr > dl;
+            if (l < r) { // a node made in the previous trip: now it has a name
+                const uint32_t me = whole ? 0u : right ? r : l;
+#pragma unroll
+                for (int a = 0; a < 6; a++) s_box[a][me] = bx[a];
+                s_height[me] = h;
+                s_info[me] = 0x80000000u | (r << 18) | (l << 9) | split;
+            }
+            if (whole) break;
+            const int gp = right ? (int)r : (int)l - 1; // the parent's split
+            exit_gp = gp;
+            if (gp < 0 || gp >= (int)kChunk - 1) break; // the sibling lies in another chunk
+            // (Everything the two children exchange is in LDS, and a wave's LDS operations are carried out in the order
+            // it issues them: the box is in place before the flag, and read after it.  The compiler must keep that
+            // order; a fence of the memory model would also wait for the stores to global memory still in flight.)
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            const uint32_t other = atomicExch(&s_flag[gp], (right ? l : r) + 1u);
+            if (other == 0u) break; // the first to arrive
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            const uint32_t far = other - 1u;
+            const uint32_t sib = right ? (uint32_t)gp + 1u : (uint32_t)gp; // the sibling's name (or position, for a leaf)
+            const bool sib_leaf = right ? far == sib : far == sib;
+            float sb[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) sb[a] = sib_leaf ? s_leaf[a][sib] : s_box[a][sib];
+            const uint32_t sh = sib_leaf ? 0u : s_height[sib];
+#pragma unroll
+            for (int a = 0; a < 3; a++) bx[a] = fminf(bx[a], sb[a]), bx[3 + a] = fmaxf(bx[3 + a], sb[3 + a]);
+            h = 1u + (h > sh ? h : sh);
+            if (right) r = far; else l = far;
+            split = (uint32_t)gp;
+            s_flag[gp] = kMerged;
+            exit_gp = -2;
+        }
+    }
+    __syncthreads();
+    // every node made here, by the lane of its name: its record, its links, the fine cut's records of its small
+    // children; the names nobody made go on the list
+    const bool valid = i + 1u < n;
+    const uint32_t info = s_info[t];
+    const bool made = valid && (info >> 31) != 0u;
+    uint32_t c0 = 0, c1 = 0;
+    uint2 leaves = make_uint2(0u, 0u);
+    float b0[6] = {0, 0, 0, 0, 0, 0}, b1[6] = {0, 0, 0, 0, 0, 0};
+    if (made) {
+        const uint32_t g = info & 511u, l = (info >> 9) & 511u, r = (info >> 18) & 511u;
+        const bool leaf0 = l == g, leaf1 = g + 1u == r;
+        c0 = (base + g) | (leaf0 ? 0x80000000u : 0u), c1 = (base + g + 1u) | (leaf1 ? 0x80000000u : 0u);
+        leaves = make_uint2(base + l, base + r);
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            b0[a] = leaf0 ? s_leaf[a][g] : s_box[a][g];
+            b1[a] = leaf1 ? s_leaf[a][g + 1u] : s_box[a][g + 1u];
+        }
+        float4* nd = (float4*)nodes + 4 * (size_t)i;
+        nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+        nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+        nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+        nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
+        // (the record is all of the node there is: who asks for child or parent arrays gets them made from the records)
+        if (s_delta[l] < 0 && s_delta[r + 1u] < 0) { // the root: one chunk holds it all
+            float4* ub = (float4*)union_box; // (its box and height, for the build's summary)
+            ub[0] = make_float4(s_box[0][t], s_box[1][t], s_box[2][t], s_box[3][t]);
+            ub[1] = make_float4(s_box[4][t], s_box[5][t], __uint_as_float(s_height[t]), 0.0f);
+            *root_done = 1u;
+        }
+    }
+    emit_fine<(int)kChunk>(made, c0, leaves, b0, b1, fine, fine_count, fine_cap);
+    // The tops, in leaf order: the lane that carried a subtree to where it stopped holds it, and the lanes' own leaves
+    // lie in their subtrees, so the order of the lanes is the order of the subtrees.
+    const bool top = t < count && exit_gp != -2 && (exit_gp < 0 || exit_gp >= (int)kChunk - 1 || s_flag[exit_gp] != kMerged);
+    const uint32_t lane = t & 63u, wave = t >> 6;
+    const uint64_t m = __ballot(top), mm = __ballot(made);
+    if (lane == 0) s_wcount[wave] = (uint32_t)__popcll(m), s_wmade[wave] = (uint32_t)__popcll(mm);
+    __syncthreads();
+    uint32_t at = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0, nmade = 0;
+    for (uint32_t w = 0; w < kChunk / 64; w++) {
+        if (w < wave) at += s_wcount[w];
+        total += s_wcount[w], nmade += s_wmade[w];
+    }
+    if (t == 0) {
+        top_counts[chunk] = total;
+        if (total > kTopCap) *overflow = 1u;
+        if (nmade) atomicAdd(finished_count, nmade);
+    }
+    if (top && at < kTopCap) {
+        float4* o = tops + 3 * ((size_t)chunk * kTopCap + at);
+        o[0] = make_float4(bx[0], bx[1], bx[2], __uint_as_float(base + l));
+        o[1] = make_float4(bx[3], bx[4], bx[5], __uint_as_float(base + r));
+        o[2] = make_float4(__uint_as_float((uint32_t)(s_delta[l] + 1) | ((uint32_t)(s_delta[r + 1u] + 1) << 8) | (h << 16)), 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// The same merging one level up: a workgroup takes the tops of kLevelUnits consecutive units (chunks, or workgroups of
+// the level below) as its items, in leaf order, and hands up its own tops.  A lane carries one item at a time; nobody
+// waits for anybody (the second child to arrive at a split goes on, the first stops), so a lane can carry several one
+// after the other.  The time of such a workgroup is the longest chain of merges from an item to the top, one lane
+// busy, so the loop does the least it can: it leaves every node it makes in LDS, under the node's split (box, leaves,
+// children, name), and a lane per node writes the records to memory afterwards.  (A loop that also named, recorded
+// and linked its nodes took three times as long: some 400 instructions a trip, issued one wave at a time.)
+// A reference to a child or a top: an item's index, or 0x8000 | the split of a node made here.
+__global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __restrict__ tops_in, const uint32_t* __restrict__ counts_in,
+                                                     uint32_t nunits, uint32_t n, float4* __restrict__ tops_out,
+                                                     uint32_t* __restrict__ counts_out, float* __restrict__ union_box, float* __restrict__ nodes,
+                                                     uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
+                                                     uint32_t* __restrict__ finished_count, float* __restrict__ fine,
+                                                     uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
+    // (gfx950 lets one workgroup have all 160 KiB of a CU's LDS; these workgroups are few and run one per CU)
+    __shared__ float s_ibox[6][kLevelItems];  // the items: box, first and last leaf, height
+    __shared__ uint32_t s_il[kLevelItems], s_ir[kLevelItems], s_ih[kLevelItems];
+    __shared__ float s_nbox[6][kLevelItems];  // the nodes made here, by split: box, first and last leaf, height,
+    __shared__ uint32_t s_nl[kLevelItems], s_nr[kLevelItems], s_nh[kLevelItems]; // ...
+    __shared__ uint32_t s_nch[kLevelItems];   // ... left child | right child << 16 (references),
+    __shared__ uint32_t s_nit[kLevelItems];   // ... first item | last item << 16,
+    __shared__ uint32_t s_nme[kLevelItems];   // ... and name
+    __shared__ int s_delta[kLevelItems + 1];  // [k + 1]: prefix between items k and k + 1; [0], [M]: at the ends
+    __shared__ uint32_t s_flag[kLevelItems];  // per split: 0, or (far item | reference << 16) + 1 of the first child, or kMerged
+    __shared__ uint32_t s_exit[kLevelItems];  // per carried item: reference | (split it waits at + 1) << 16; 0xFFFFFFFF: nothing left
+    __shared__ uint32_t s_off[kLevelUnits + 1], s_wcount[kLevelThreads / 64], s_made, s_nfine, s_fbase;
+    __shared__ float4 s_fine[2 * kLevelFine]; // the fine cut's records made here, written out together at the end
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t u0 = blockIdx.x * kLevelUnits, nu = min(kLevelUnits, nunits - u0);
+    static_assert(kLevelUnits <= 64u && kLevelItems <= 0x8000u, "one wave adds up the units' counts; references fit 16 bits");
+    if (tid < 64u) {
+        const uint32_t c = tid < nu ? min(counts_in[u0 + tid], kTopCap) : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += v;
+        }
+        if (tid < nu) s_off[tid] = incl - c;
+        if (tid == nu - 1u) s_off[nu] = incl;
+        if (tid == 0) s_made = 0u, s_nfine = 0u;
+    }
+    __syncthreads();
+    const uint32_t M = s_off[nu];
+    if (M > kLevelItems) { // block-uniform: more tops than fit (a very unbalanced tree)
+        if (tid == 0) *overflow = 1u, counts_out[blockIdx.x] = 0u;
+        return;
+    }
+    for (uint32_t k = tid; k < M; k += kLevelThreads) {
+        uint32_t u = 0;
+        while (s_off[u + 1u] <= k) u++;
+        const float4* it = tops_in + 3 * ((size_t)(u0 + u) * kTopCap + (k - s_off[u]));
+        const float4 a = it[0], b = it[1], c = it[2];
+        s_ibox[0][k] = a.x, s_ibox[1][k] = a.y, s_ibox[2][k] = a.z, s_ibox[3][k] = b.x, s_ibox[4][k] = b.y, s_ibox[5][k] = b.z;
+        s_il[k] = __float_as_uint(a.w), s_ir[k] = __float_as_uint(b.w);
+        const uint32_t w = __float_as_uint(c.x);
+        s_ih[k] = w >> 16, s_flag[k] = 0u;
+        s_delta[k + 1u] = (int)((w >> 8) & 255u) - 1;
+        if (k == 0) s_delta[0] = (int)(w & 255u) - 1;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < M; k += kLevelThreads) {
+        uint32_t il = k, ir = k, l = s_il[k], r = s_ir[k], h = s_ih[k], ref = k, exit = 0xFFFFFFFFu;
+        float bx[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) bx[a] = s_ibox[a][k];
+        for (;;) {
+            const int dl = s_delta[il], dr = s_delta[ir + 1u];
+            const bool whole = dl < 0 && dr < 0; // the root
+            const bool right = dr > dl;
+            if (ref & 0x8000u) s_nme[ref & 0x7FFFu] = whole ? 0u : right ? r : l; // the node made in the previous trip gets its name
+            if (whole) break;
+            const int gp = right ? (int)ir : (int)il - 1; // the parent's split, in items
+            exit = ref | ((uint32_t)(gp + 1) << 16);
+            if (gp < 0 || gp >= (int)M - 1) break; // the sibling lies in another workgroup's units
+            __atomic_signal_fence(__ATOMIC_SEQ_CST); // (LDS only: see k_build_chunks)
+            const uint32_t other = atomicExch(&s_flag[gp], ((right ? il : ir) | (ref << 16)) + 1u);
+            if (other == 0u) break; // the first to arrive
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            const uint32_t far = (other - 1u) & 0xFFFFu, sref = (other - 1u) >> 16, si = sref & 0x7FFFu;
+            const bool snode = (sref & 0x8000u) != 0u;
+            float sb[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) sb[a] = snode ? s_nbox[a][si] : s_ibox[a][si];
+            const uint32_t sl = snode ? s_nl[si] : s_il[si], sr = snode ? s_nr[si] : s_ir[si], sh = snode ? s_nh[si] : s_ih[si];
+#pragma unroll
+            for (int a = 0; a < 3; a++) bx[a] = fminf(bx[a], sb[a]), bx[3 + a] = fmaxf(bx[3 + a], sb[3 + a]);
+            h = 1u + (h > sh ? h : sh);
+            if (right) r = sr, ir = far; else l = sl, il = far;
+            const uint32_t g = (uint32_t)gp;
+#pragma unroll
+            for (int a = 0; a < 6; a++) s_nbox[a][g] = bx[a];
+            s_nl[g] = l, s_nr[g] = r, s_nh[g] = h, s_nit[g] = il | (ir << 16);
+            s_nch[g] = right ? (ref | (sref << 16)) : (sref | (ref << 16));
+            ref = 0x8000u | g;
+            s_flag[g] = kMerged;
+            exit = 0xFFFFFFFFu;
+        }
+        s_exit[k] = exit;
+    }
+    __syncthreads();
+    // every node made here, a lane each: its record, its links, the fine cut's records of its small children
+    uint32_t made = 0;
+    for (uint32_t g = tid; g + 1u < M; g += kLevelThreads) {
+        if (s_flag[g] != kMerged) continue;
+        made++;
+        const uint32_t me = s_nme[g], l = s_nl[g], r = s_nr[g], ch = s_nch[g];
+        const uint32_t r0 = ch & 0xFFFFu, r1 = ch >> 16, i0 = r0 & 0x7FFFu, i1 = r1 & 0x7FFFu;
+        const bool n0 = (r0 & 0x8000u) != 0u, n1 = (r1 & 0x8000u) != 0u;
+        float b0[6], b1[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) b0[a] = n0 ? s_nbox[a][i0] : s_ibox[a][i0], b1[a] = n1 ? s_nbox[a][i1] : s_ibox[a][i1];
+        const uint32_t gamma = n0 ? s_nr[i0] : s_ir[i0]; // last leaf of the left child
+        const bool leaf0 = l == gamma, leaf1 = gamma + 1u == r;
+        const uint32_t c0 = gamma | (leaf0 ? 0x80000000u : 0u), c1 = (gamma + 1u) | (leaf1 ? 0x80000000u : 0u);
+        float4* nd = (float4*)nodes + 4 * (size_t)me;
+        nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+        nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+        nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+        nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(l), __uint_as_float(r));
+        if (l == 0u && r == n - 1u) { // the root: its box and height, for the build's summary
+            float4* ub = (float4*)union_box;
+            ub[0] = make_float4(s_nbox[0][g], s_nbox[1][g], s_nbox[2][g], s_nbox[3][g]);
+            ub[1] = make_float4(s_nbox[4][g], s_nbox[5][g], __uint_as_float(s_nh[g]), 0.0f);
+            *root_done = 1u;
+        }
+        const uint32_t c0n = gamma - l + 1u, c1n = r - gamma;
+        const bool big = r - l + 1u > kFineMax;
+        const bool f0 = big && c0n <= kFineMax, f1 = big && c1n <= kFineMax;
+        if (f0 || f1) {
+            // collected in LDS and written out together: one update of the counter in memory per workgroup
+            const uint32_t cnt = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
+            const uint32_t at = atomicAdd(&s_nfine, cnt);
+            const uint32_t nlocal = at < kLevelFine ? min(cnt, kLevelFine - at) : 0u; // of this node's records, in LDS
+            const uint32_t gat = nlocal < cnt ? atomicAdd(fine_count, cnt - nlocal) : 0u;
+            uint32_t j = 0;
+            if (f0) {
+                const float4 q0 = make_float4(b0[0], b0[1], b0[2], __uint_as_float(l));
+                const float4 q1 = make_float4(b0[3], b0[4], b0[5], __uint_as_float(c0n));
+                if (j < nlocal)
+                    s_fine[2 * (at + j)] = q0, s_fine[2 * (at + j) + 1] = q1;
+                else if (gat + j - nlocal < fine_cap)
+                    ((float4*)fine)[2 * (size_t)(gat + j - nlocal)] = q0, ((float4*)fine)[2 * (size_t)(gat + j - nlocal) + 1] = q1;
+                j++;
+            }
+            if (f1) {
+                const float4 q0 = make_float4(b1[0], b1[1], b1[2], __uint_as_float(gamma + 1u));
+                const float4 q1 = make_float4(b1[3], b1[4], b1[5], __uint_as_float(c1n));
+                if (j < nlocal)
+                    s_fine[2 * (at + j)] = q0, s_fine[2 * (at + j) + 1] = q1;
+                else if (gat + j - nlocal < fine_cap)
+                    ((float4*)fine)[2 * (size_t)(gat + j - nlocal)] = q0, ((float4*)fine)[2 * (size_t)(gat + j - nlocal) + 1] = q1;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) made += __shfl_down(made, off);
+    if (lane == 0 && made) atomicAdd(&s_made, made);
+    // the tops this workgroup hands up, in leaf order (the carried item lies in the subtree it was carried into)
+    uint32_t before = 0; // tops of the rounds before this one
+    for (uint32_t k0 = 0; k0 < M; k0 += kLevelThreads) { // block-uniform
+        const uint32_t k = k0 + tid;
+        bool top = false;
+        uint32_t e = 0;
+        if (k < M) {
+            e = s_exit[k];
+            const int gp = (int)(e >> 16) - 1;
+            top = e != 0xFFFFFFFFu && (gp < 0 || gp >= (int)M - 1 || s_flag[gp] != kMerged);
+        }
+        const uint64_t m = __ballot(top);
+        __syncthreads(); // s_wcount of the round before has been read
+        if (lane == 0) s_wcount[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t at = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), round = 0;
+        for (uint32_t w = 0; w < kLevelThreads / 64u; w++) {
+            if (w < wave) at += s_wcount[w];
+            round += s_wcount[w];
+        }
+        if (top && at < kTopCap) {
+            const uint32_t ref = e & 0xFFFFu, i = ref & 0x7FFFu;
+            const bool nd = (ref & 0x8000u) != 0u;
+            const uint32_t il = nd ? s_nit[i] & 0xFFFFu : i, ir = nd ? s_nit[i] >> 16 : i;
+            float4* o = tops_out + 3 * ((size_t)blockIdx.x * kTopCap + at);
+            o[0] = make_float4(nd ? s_nbox[0][i] : s_ibox[0][i], nd ? s_nbox[1][i] : s_ibox[1][i], nd ? s_nbox[2][i] : s_ibox[2][i],
+                               __uint_as_float(nd ? s_nl[i] : s_il[i]));
+            o[1] = make_float4(nd ? s_nbox[3][i] : s_ibox[3][i], nd ? s_nbox[4][i] : s_ibox[4][i], nd ? s_nbox[5][i] : s_ibox[5][i],
+                               __uint_as_float(nd ? s_nr[i] : s_ir[i]));
+            o[2] = make_float4(__uint_as_float((uint32_t)(s_delta[il] + 1) | ((uint32_t)(s_delta[ir + 1u] + 1) << 8) |
+                                               ((nd ? s_nh[i] : s_ih[i]) << 16)), 0.0f, 0.0f, 0.0f);
+        }
+        before += round;
+    }
+    __syncthreads(); // s_made and s_nfine are complete
+    // (s_nfine also counts the records that did not fit and went to memory at once: the first kLevelFine are in LDS)
+    const uint32_t nf = min(s_nfine, kLevelFine);
+    if (tid == 0) {
+        counts_out[blockIdx.x] = before;
+        if (before > kTopCap) *overflow = 1u;
+        if (s_made) atomicAdd(finished_count, s_made);
+        s_fbase = nf ? atomicAdd(fine_count, nf) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < nf; q += kLevelThreads)
+        if (s_fbase + q < fine_cap) {
+            ((float4*)fine)[2 * (size_t)(s_fbase + q)] = s_fine[2 * q];
+            ((float4*)fine)[2 * (size_t)(s_fbase + q) + 1] = s_fine[2 * q + 1];
+        }
 }
 
 // The box and height of a child: a leaf's from its triangle, a node's from what the node left in union_box.  The
@@ -862,13 +1261,15 @@ static uint32_t refit_spans_for(uint32_t n) { return (refit_chunks_for(n) + kSpa
 // than the rest of the chunk kernel), then the summary the cut kernel writes; one copy fetches them all.
 constexpr uint32_t kWordStride = 64;
 enum : uint32_t { kWFinishedChunks = 0, kWFinishedClimb = kWordStride, kWRootDone = 2 * kWordStride, kWFineCount = 3 * kWordStride,
-                  kWUnsorted = 4 * kWordStride, kWSummary = 5 * kWordStride, kWords = 5 * kWordStride + 16 };
+                  kWUnsorted = 4 * kWordStride, kWSummary = 5 * kWordStride, kWOverflow = 6 * kWordStride, kWords = 7 * kWordStride };
 static_assert(kSummaryWords <= 16, "the summary has sixteen words");
+static uint32_t level_units_for(uint32_t units) { return (units + kLevelUnits - 1) / kLevelUnits; }
+static size_t level_tops_bytes(uint32_t units) { return (size_t)units * kTopCap * 48; }
 static size_t build_words_for(uint32_t n) { return kWords + (size_t)refit_spans_for(n) * 2 * 8; }
 
 size_t lbvh_keep_bytes(uint32_t n) {
     if (n < 2) return 0;
-    const size_t sizes[] = {(size_t)n * 8, (size_t)n * 4, (size_t)(n - 1) * 8, (size_t)(n - 1) * 4, (size_t)n * 4,
+    const size_t sizes[] = {(size_t)n * 8, (size_t)n * 4,
                             (size_t)(n - 1) * 64, (size_t)kCutCap * 32, (size_t)(kCutCap / kCutGroup) * 32,
                             (size_t)fine_cap_for(n) * 32, (size_t)n * 4};
     size_t total = 0;
@@ -881,14 +1282,17 @@ size_t lbvh_scratch_bytes(uint32_t n) {
     const size_t ntiles = sort_tiles_for(n);
     const size_t sizes[] = {(size_t)bounds_blocks_for(n) * 24, 32, (size_t)n * 8, (size_t)n * 4, ntiles * 256 * 4,
                             (size_t)(n - 1) * 4, (ntiles * 256 / kScanBlock + 2) * 4, (size_t)refit_chunks_for(n) * 64,
-                            build_words_for(n) * 4, (size_t)(n - 1) * 32, (size_t)(n - 1) * 8};
+                            build_words_for(n) * 4, (size_t)(n - 1) * 32, (size_t)(n - 1) * 8,
+                            (size_t)(n - 1) * 8, (size_t)(n - 1) * 4, (size_t)n * 4,
+                            level_tops_bytes(refit_chunks_for(n)), level_tops_bytes(level_units_for(refit_chunks_for(n))),
+                            (size_t)refit_chunks_for(n) * 4, (size_t)level_units_for(refit_chunks_for(n)) * 4};
     size_t total = 0;
     for (size_t b : sizes) total += Arena::aligned(b);
     return total;
 }
 
 static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
-                                  const float* bounds, const MeshSource& mesh, int sort_shift);
+                                  const float* bounds, const MeshSource& mesh, int sort_shift, bool search_all, bool* overflowed);
 
 float* lbvh_take_bounds(Arena& tmp, uint32_t n) { return n < 2 ? nullptr : tmp.take<float>((size_t)bounds_blocks_for(n) * 24); }
 
@@ -901,17 +1305,25 @@ hipError_t build_lbvh(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, c
     int at = sort_hint ? *sort_hint : 0;
     at = at < 0 ? 0 : at > 2 ? 2 : at;
     const size_t keep_used = keep.used, tmp_used = tmp.used;
+    // INV_BUILD_SEARCH=1 in the environment: every node finds its range by searching (k_karras), the chunks only refit
+    // and the nodes across chunk boundaries are climbed through memory, as before the chunks and the levels above them
+    // built the hierarchy bottom-up (for measurements and as a cross-check).  A tree so unbalanced that a unit has more
+    // tops than it can hand up is built that way too.
+    static const bool search_env = getenv("INV_BUILD_SEARCH") && atoi(getenv("INV_BUILD_SEARCH"));
+    bool search_all = search_env;
     hipError_t e = hipErrorNotReady;
     for (; at < 3 && e == hipErrorNotReady; at++) {
         keep.used = keep_used, tmp.used = tmp_used;
-        e = build_lbvh_with(s, sc, keep, tmp, records, bounds, mesh, shifts[at]);
+        bool overflowed = false;
+        e = build_lbvh_with(s, sc, keep, tmp, records, bounds, mesh, shifts[at], search_all, &overflowed);
+        if (e == hipErrorNotReady && overflowed) search_all = true, at--; // the same sort again, the other hierarchy
     }
     if (sort_hint && e == hipSuccess) *sort_hint = at - 1;
     return e;
 }
 
 static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, Arena& tmp, const float* records,
-                                  const float* bounds, const MeshSource& mesh, int sort_shift) {
+                                  const float* bounds, const MeshSource& mesh, int sort_shift, bool search_all, bool* overflowed) {
     const uint32_t n = sc.ntri;
     sc.has_bvh = false;
     if (n < 2) return hipSuccess; // nothing to build: such scenes render through the brute-force kernel
@@ -931,12 +1343,19 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     uint4* const handed = (uint4*)(words + kWords);
     float* union_box = tmp.take<float>((size_t)(n - 1) * 32);
     uint2* range = tmp.take<uint2>((size_t)(n - 1) * 8);
+    // the tops the chunks hand up, and those of the levels above them in turn (two sets, used alternately)
+    const uint32_t nunits2 = level_units_for(nchunks);
+    float4* tops[2] = {tmp.take<float4>(level_tops_bytes(nchunks)), tmp.take<float4>(level_tops_bytes(nunits2))};
+    uint32_t* top_counts[2] = {tmp.take<uint32_t>((size_t)nchunks * 4), tmp.take<uint32_t>((size_t)nunits2 * 4)};
     // what the scene keeps
     sc.morton = keep.take<uint64_t>((size_t)n * 8);
     sc.order = keep.take<uint32_t>((size_t)n * 4);
-    sc.child = keep.take<uint32_t>((size_t)(n - 1) * 8);
-    sc.parent = keep.take<uint32_t>((size_t)(n - 1) * 4);
-    sc.leaf_parent = keep.take<uint32_t>((size_t)n * 4);
+    // (links of the build that searches; the scene keeps the node records only: inv_scene_read_lbvh makes its child and
+    // parent arrays from those)
+    sc.child = sc.parent = sc.leaf_parent = nullptr;
+    uint32_t* const b_child = tmp.take<uint32_t>((size_t)(n - 1) * 8);
+    uint32_t* const b_parent = tmp.take<uint32_t>((size_t)(n - 1) * 4);
+    uint32_t* const b_leaf_parent = tmp.take<uint32_t>((size_t)n * 4);
     sc.nodes = keep.take<float>((size_t)(n - 1) * 64);
     sc.cut = keep.take<float>((size_t)kCutCap * 32);
     sc.cut_groups = keep.take<float>((size_t)(kCutCap / kCutGroup) * 32);
@@ -944,7 +1363,7 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     sc.fine = keep.take<float>((size_t)fine_cap * 32);
     sc.nfine = 0;
     sc.slot_of = keep.take<uint32_t>((size_t)n * 4);
-    if (!range || !sc.cut_groups || !sc.fine || !sc.slot_of) return hipErrorOutOfMemory; // the arenas were sized for something else
+    if (!range || !top_counts[1] || !b_leaf_parent || !sc.cut_groups || !sc.fine || !sc.slot_of) return hipErrorOutOfMemory; // the arenas were sized for something else
     float4 *A1 = (float4*)sc.triA, *B1 = (float4*)sc.triB, *C1 = (float4*)sc.triC;
 
     const float4* T0 = (const float4*)records;
@@ -985,26 +1404,43 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     if (sort_shift)
         hipLaunchKernelGGL(k_sort_runs, grid_n, blk, 0, s, (const uint64_t*)kin, (const uint32_t*)vin, n, sort_shift, kout, vout,
                            too_long);
-    hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, sc.child, sc.parent, sc.leaf_parent,
-                       range);
+    if (search_all)
+        hipLaunchKernelGGL(k_karras, dim3(xcd_grid((n - 1 + 255) / 256)), blk, 0, s, sc.morton, n, b_child, b_parent, b_leaf_parent,
+                           range);
     uint32_t* fine_count = words + kWFineCount;
     // (the inverse order is a scatter of four bytes per triangle all over memory, and only the resolve pass of frames
     // drawn one lane per triangle reads it -- unless it assembles its winners from the cached mesh)
     if (mesh.xyzw && mesh_draw_enabled()) sc.slot_of = nullptr;
-    hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, mesh, (const uint32_t*)sc.order, sc.slot_of, A1, B1,
-                       C1, sc.child, sc.parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
-                       words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
-    // the nodes that cross chunk boundaries: a workgroup per span of chunks as far as the spans go, one for the rest
-    if (nspans > 1)
-        hipLaunchKernelGGL(k_refit_climb, dim3(nspans), dim3(kClimbThreads), 0, s, (const float4*)A1, (const float4*)B1,
-                           (const float4*)C1, sc.child, sc.parent, range, (const uint4*)slots, 2u * nchunks, 2u * kSpanChunks,
-                           kSpanChunks * kChunk, handed, arrive, union_box, sc.nodes, words + kWFinishedClimb, words + kWRootDone,
-                           sc.fine, fine_count, fine_cap);
-    if (nchunks > 1)
-        hipLaunchKernelGGL(k_refit_climb, dim3(1), dim3(kClimbThreads), 0, s, (const float4*)A1, (const float4*)B1,
-                           (const float4*)C1, sc.child, sc.parent, range, (const uint4*)(nspans > 1 ? handed : slots),
-                           2u * (nspans > 1 ? nspans : nchunks), 2u * (nspans > 1 ? nspans : nchunks), 0u, (uint4*)nullptr, arrive,
-                           union_box, sc.nodes, words + kWFinishedClimb, words + kWRootDone, sc.fine, fine_count, fine_cap);
+    if (search_all) {
+        hipLaunchKernelGGL(k_refit_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, mesh, (const uint32_t*)sc.order, sc.slot_of, A1, B1,
+                           C1, b_child, b_parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
+                           words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
+    } else {
+        hipLaunchKernelGGL(k_build_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, mesh, (const uint32_t*)sc.order,
+                           (const uint64_t*)sc.morton, sc.slot_of, A1, B1, C1, n, union_box, sc.nodes, tops[0], top_counts[0], words + kWOverflow, words + kWRootDone,
+                           words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
+        int in = 0;
+        for (uint32_t units = nchunks; units > 1u; in ^= 1) {
+            const uint32_t wgs = level_units_for(units);
+            hipLaunchKernelGGL(k_build_level, dim3(wgs), dim3(kLevelThreads), 0, s, (const float4*)tops[in], (const uint32_t*)top_counts[in],
+                               units, n, tops[in ^ 1], top_counts[in ^ 1], union_box, sc.nodes,
+                               words + kWOverflow, words + kWRootDone, words + kWFinishedClimb, sc.fine, fine_count, fine_cap);
+            units = wgs;
+        }
+    }
+    if (search_all) {
+        // the nodes that cross chunk boundaries: a workgroup per span of chunks as far as the spans go, one for the rest
+        if (nspans > 1)
+            hipLaunchKernelGGL(k_refit_climb, dim3(nspans), dim3(kClimbThreads), 0, s, (const float4*)A1, (const float4*)B1,
+                               (const float4*)C1, b_child, b_parent, range, (const uint4*)slots, 2u * nchunks, 2u * kSpanChunks,
+                               kSpanChunks * kChunk, handed, arrive, union_box, sc.nodes, words + kWFinishedClimb, words + kWRootDone,
+                               sc.fine, fine_count, fine_cap);
+        if (nchunks > 1)
+            hipLaunchKernelGGL(k_refit_climb, dim3(1), dim3(kClimbThreads), 0, s, (const float4*)A1, (const float4*)B1,
+                               (const float4*)C1, b_child, b_parent, range, (const uint4*)(nspans > 1 ? handed : slots),
+                               2u * (nspans > 1 ? nspans : nchunks), 2u * (nspans > 1 ? nspans : nchunks), 0u, (uint4*)nullptr, arrive,
+                               union_box, sc.nodes, words + kWFinishedClimb, words + kWRootDone, sc.fine, fine_count, fine_cap);
+    }
     hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
                        (const uint32_t*)(words + kWRootDone), (const uint32_t*)too_long, (const float*)d_bbox,
                        (const float*)union_box, words + kWSummary);
@@ -1014,6 +1450,10 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     HIP_RET(hipMemcpyAsync(host_words, words, sizeof host_words, hipMemcpyDeviceToHost, s));
     HIP_RET(hipStreamSynchronize(s)); // the caller frees the scratch arena after this returns
     if (sort_shift && host_words[kWUnsorted] != 0u) return hipErrorNotReady; // the caller sorts again with more passes
+    if (host_words[kWOverflow] != 0u) { // a unit with more tops than it can hand up: the caller builds the other way
+        *overflowed = true;
+        return hipErrorNotReady;
+    }
     const uint64_t finished = (uint64_t)host_words[kWFinishedChunks] + host_words[kWFinishedClimb];
     if (finished != n - 1 || host_words[kWRootDone] == 0u || summary[0] == kCutUnfinished) return hipErrorUnknown; // every internal node must have been refitted
     sc.ncut = summary[0];

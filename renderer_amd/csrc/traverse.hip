@@ -2361,7 +2361,7 @@ bool mesh_draw_enabled() {
 bool scatter_wanted(const FrameK& f, const DeviceScene& sc, const Outputs& out) {
     // (the resolve pass finds a winner's triangle through slot_of or in the cached mesh)
     if (f.npix == 0 || !sc.has_bvh || !(sc.slot_of || (sc.mesh_cached && mesh_draw_enabled())) || f.spp != 1u) return false;
-    if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE | INV_BLOCKS)) return false;
+    if (f.flags & (INV_LANE_TRAVERSAL | INV_BRUTE_FORCE | INV_BLOCKS | INV_TILE_TRAVERSAL)) return false;
     const int env = scatter_env();
     if (env == 0 || !eye_outside_scene(f, sc)) return false;
     if (env > 0) return true;

@@ -104,7 +104,7 @@ def oracle_params(oracle, prm):
     """The oracle's params for a draw: the same frame without the flags that only choose a GPU kernel."""
     import renderer_amd as R
     return oracle.make_params(prm.width, prm.height, prm.spp, prm.ao_rays,
-                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL | R.BLOCKS), prm.seed, ao_tmax=prm.ao_tmax)
+                              prm.flags & ~(R.BRUTE_FORCE | R.LANE_TRAVERSAL | R.BLOCKS | R.TILE_TRAVERSAL), prm.seed, ao_tmax=prm.ao_tmax)
 
 
 def planes_to_frame(planes, w, h):

@@ -94,6 +94,10 @@ def test_config4_1024_instances(oracle, gpu_ctx, bunny_path, bunny_mesh):
         common.assert_frames_equal(got2, want2, "config 4, two samples per pixel")
         hits = got[2] != 0xFFFFFFFF
         assert hits.sum() > 300000 and len(np.unique(got[2][hits] // 4968)) == 1024  # every instance is seen
+        # one sample through the LBVH on request (INV_TILE_TRAVERSAL): the same frame
+        prm_t = R.make_params(w, h, flags=FLAGS | R.TILE_TRAVERSAL)
+        assert scene.draw_path(cam, prm_t) == R.api.PATH_TILES_BATCHED | R.api.PATH_BINNED
+        common.assert_frames_equal(scene.render(cam, prm_t), want, "config 4 through the tile kernel")
         # the same frame as a batch of two on a frame slot (the form bench.py times for small scenes) and in parity mode
         prm0 = R.make_params(w, h)
         got0 = scene.render(cam, prm0)

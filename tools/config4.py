@@ -48,7 +48,8 @@ def main():
                                                           min(times[1:]), len(times) - 1))
     cam = common.grid_camera(R.camera_reference(w, h), a.side)
     buf = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
-    rows = [("auto (one sample)", 0, 1), ("auto (two samples: the tile kernel)", 0, 2)]
+    rows = [("auto (one sample)", 0, 1), ("through the LBVH (INV_TILE_TRAVERSAL)", R.TILE_TRAVERSAL, 1),
+            ("auto (two samples: the tile kernel)", 0, 2)]
     if a.side <= 40:
         rows.append(("lane traversal", R.LANE_TRAVERSAL, 1))
     for name, flags, spp in rows:
