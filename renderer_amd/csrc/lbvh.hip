@@ -624,8 +624,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
                                                          uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
                                                          uint32_t* __restrict__ finished_count, float* __restrict__ fine,
                                                          uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
-    __shared__ float s_leaf[6][kChunk];   // boxes of the chunk's leaves
-    __shared__ float s_box[6][kChunk];    // boxes of the nodes made here, by the node's name
+    __shared__ float s_b[6][2 * kChunk];  // boxes: [p] of the leaf at p, [kChunk + name] of a node made here
     __shared__ uint64_t s_key[kChunk + 2]; // keys of the chunk and of one leaf on either side
     __shared__ int s_delta[kChunk + 1];   // [p + 1]: common prefix of the keys at p and p + 1, p = -1 .. kChunk - 1; -1: no such leaf
     __shared__ uint32_t s_flag[kChunk];   // per split g (between g and g + 1): 0, or the first child's far end + 1, or kMerged
@@ -653,7 +652,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         float lo[3], hi[3];
         tri_box(a, b, c, lo, hi);
 #pragma unroll
-        for (int a = 0; a < 3; a++) s_leaf[a][t] = bx[a] = lo[a], s_leaf[3 + a][t] = bx[3 + a] = hi[a];
+        for (int a = 0; a < 3; a++) s_b[a][t] = bx[a] = lo[a], s_b[3 + a][t] = bx[3 + a] = hi[a];
     }
     s_flag[t] = 0u, s_info[t] = 0u, s_height[t] = 0u;
     __syncthreads();
@@ -676,7 +675,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
             if (l < r) { // a node made in the previous trip: now it has a name
                 const uint32_t me = whole ? 0u : right ? r : l;
 #pragma unroll
-                for (int a = 0; a < 6; a++) s_box[a][me] = bx[a];
+                for (int a = 0; a < 6; a++) s_b[a][kChunk + me] = bx[a];
                 s_height[me] = h;
                 s_info[me] = 0x80000000u | (r << 18) | (l << 9) | split;
             }
@@ -695,8 +694,9 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
             const uint32_t sib = right ? (uint32_t)gp + 1u : (uint32_t)gp; // the sibling's name (or position, for a leaf)
             const bool sib_leaf = right ? far == sib : far == sib;
             float sb[6];
+            const uint32_t sat = sib_leaf ? sib : kChunk + sib;
 #pragma unroll
-            for (int a = 0; a < 6; a++) sb[a] = sib_leaf ? s_leaf[a][sib] : s_box[a][sib];
+            for (int a = 0; a < 6; a++) sb[a] = s_b[a][sat];
             const uint32_t sh = sib_leaf ? 0u : s_height[sib];
 #pragma unroll
             for (int a = 0; a < 3; a++) bx[a] = fminf(bx[a], sb[a]), bx[3 + a] = fmaxf(bx[3 + a], sb[3 + a]);
@@ -722,10 +722,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         c0 = (base + g) | (leaf0 ? 0x80000000u : 0u), c1 = (base + g + 1u) | (leaf1 ? 0x80000000u : 0u);
         leaves = make_uint2(base + l, base + r);
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-            b0[a] = leaf0 ? s_leaf[a][g] : s_box[a][g];
-            b1[a] = leaf1 ? s_leaf[a][g + 1u] : s_box[a][g + 1u];
-        }
+        for (int a = 0; a < 6; a++) b0[a] = s_b[a][leaf0 ? g : kChunk + g], b1[a] = s_b[a][leaf1 ? g + 1u : kChunk + g + 1u];
         float4* nd = (float4*)nodes + 4 * (size_t)i;
         nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
         nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
@@ -734,8 +731,8 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         // (the record is all of the node there is: who asks for child or parent arrays gets them made from the records)
         if (s_delta[l] < 0 && s_delta[r + 1u] < 0) { // the root: one chunk holds it all
             float4* ub = (float4*)union_box; // (its box and height, for the build's summary)
-            ub[0] = make_float4(s_box[0][t], s_box[1][t], s_box[2][t], s_box[3][t]);
-            ub[1] = make_float4(s_box[4][t], s_box[5][t], __uint_as_float(s_height[t]), 0.0f);
+            ub[0] = make_float4(s_b[0][kChunk + t], s_b[1][kChunk + t], s_b[2][kChunk + t], s_b[3][kChunk + t]);
+            ub[1] = make_float4(s_b[4][kChunk + t], s_b[5][kChunk + t], __uint_as_float(s_height[t]), 0.0f);
             *root_done = 1u;
         }
     }
