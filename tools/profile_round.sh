@@ -3,7 +3,7 @@
 # passes, phase timing, per-tile statistics and the instruction-mix table.  Run on the GPU box from the repo root:
 #     bash tools/profile_round.sh TAG
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 rm -rf "$O" && mkdir -p "$O"
@@ -34,4 +34,14 @@ bash tools/pmc_ao.sh > /dev/null 2>&1 && cp gpurun_out/pmc_ao.txt "$O/pmc_ao.txt
 bash tools/pmc_4k.sh > "$O/pmc_4k.txt" 2>&1
 bash tools/pmc_x1024.sh > "$O/pmc_x1024.txt" 2>&1
 timeout -k 10 200 python3 tools/build_probe.py > "$O/build_probe.txt" 2>&1
+# the 5 M-triangle frame and its scene builds: kernel statistics and HBM bytes (FETCH_SIZE, WRITE_SIZE: a pass each)
+BX="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 2 --warmup 1 --warmup-ms 0 --frames-per-step 8 --workload bunny_x1024_1080p"
+(cd /tmp && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_x1024" -- $BX > /dev/null 2>&1)
+(cd /tmp && timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch_x1024" -- $BX > /dev/null 2>&1)
+(cd /tmp && timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write_x1024" -- $BX > /dev/null 2>&1)
+bash tools/pmc_read_hit.sh > /dev/null 2>&1 && cp gpurun_out/pmc_read_hit.txt "$O/pmc_read_hit.txt"
+timeout -k 10 250 python3 bench.py --workload bunny_x13924_1080p --no-cpu-baseline --steps 3 --warmup 1 --frames-per-step 8 > "$O/bench_x13924.json"
+timeout -k 10 250 python3 tools/config4.py --side 118 --builds 5 > "$O/config4_118.txt" 2>&1
+timeout -k 10 120 python3 tools/memset_probe.py > "$O/memset_probe.txt" 2>&1
+INVERT_HIP_LIB=$R/renderer_amd/libinvert_hip_timing.so timeout -k 10 200 python3 tools/fill_probe.py timing-build > "$O/fill_probe.txt" 2>&1
 echo done
