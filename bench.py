@@ -859,20 +859,24 @@ def main():
             # the instruction counts of the kernel's counter pass
             result["cpu_baseline"]["oracle_traversal_work"] = work
         if valu_bound:
-            # The frame is bound by vector arithmetic: the roofline is the fp32 vector peak.  `achieved` = the
-            # algorithmic flops of a per-ray LBVH traversal of this frame (the oracle's own test counts: 20 per ray,
-            # 22 per box test, 51 per triangle test, 15 per shaded hit) over this run's time per frame; what the
-            # kernel's counter pass saw (issue slots, active lanes) stays under roofline.valu, and the HBM view of
-            # the same run is kept beside it.
+            # The frame is bound by vector arithmetic: the roofline is the fp32 vector peak.  Instructions cannot be
+            # counted inside this process, so `achieved` = the vector instructions the newest committed counter pass of this
+            # workload saw per launch of each of the frame's kernels (times the lanes active, 2 flops each as if all were
+            # multiply-adds) over THIS run's time per frame; the HBM view of the same run is kept beside it.  Without
+            # such a pass the line keeps the HBM view.
             r = result["roofline"]
-            hbm_view = {k: r[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes", "traffic")}
-            flops = basis = None
-            if result["cpu_baseline"]:
-                flops, basis = float(result["cpu_baseline"]["oracle_traversal_work"]["flops"]), "algorithmic flops of the oracle's traversal of this frame"
+            flops, used = 0.0, []
+            for k in ("k_render_tile", "k_ao"):
+                v = pmc_valu(args.workload, world, k)
+                if v and v.get("valu_instructions_per_launch"):
+                    flops += v["valu_instructions_per_launch"] * v["lanes_active"] * 128.0
+                    used.append("%s (%s)" % (k, v["source"]))
             if flops:
+                hbm_view = {k: r[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes", "traffic")}
                 tf = flops * nframes / elapsed / 1e12
                 r.update({"bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
-                          "flops_per_frame": flops, "flops_basis": basis, "hbm": hbm_view})
+                          "flops_per_frame": flops, "flops_basis": "vector instructions x active lanes x 2 of " + ", ".join(used),
+                          "per_launch_frac": None, "hbm": hbm_view})
         print(json.dumps(result))
     if comm is not None:
         comm.close()

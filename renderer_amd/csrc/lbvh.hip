@@ -723,12 +723,8 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         leaves = make_uint2(base + l, base + r);
 #pragma unroll
         for (int a = 0; a < 6; a++) b0[a] = s_b[a][leaf0 ? g : kChunk + g], b1[a] = s_b[a][leaf1 ? g + 1u : kChunk + g + 1u];
-        float4* nd = (float4*)nodes + 4 * (size_t)i;
-        nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
-        nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
-        nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
-        nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
-        // (the record is all of the node there is: who asks for child or parent arrays gets them made from the records)
+        // (the record -- written below -- is all of the node there is: who asks for child or parent arrays gets them made
+        // from the records)
         if (s_delta[l] < 0 && s_delta[r + 1u] < 0) { // the root: one chunk holds it all
             float4* ub = (float4*)union_box; // (its box and height, for the build's summary)
             ub[0] = make_float4(s_b[0][kChunk + t], s_b[1][kChunk + t], s_b[2][kChunk + t], s_b[3][kChunk + t]);
@@ -737,6 +733,33 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         }
     }
     emit_fine<(int)kChunk>(made, c0, leaves, b0, b1, fine, fine_count, fine_cap);
+    // The records of the nodes made here.  A lane that stored its own 64 bytes would make every store instruction of
+    // the wave touch 64 different lines, 16 bytes of each; through LDS (the boxes' array, which nobody reads any more:
+    // emit_fine ended with a barrier) a wave's records leave as four instructions of 1 KiB of consecutive bytes each.
+    // Half of the waves at a time: the array holds 256 records.
+    {
+        float4* const stage = (float4*)&s_b[0][0] + 4u * (t & 255u); // this lane's record
+        const uint32_t lane = t & 63u;
+        const uint64_t mm = __ballot(made);
+        for (uint32_t half = 0; half < 2u; half++) { // block-uniform
+            if ((t >> 8) == half) {
+                stage[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+                stage[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+                stage[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+                stage[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
+                // (a wave reads only what it wrote itself, and LDS carries a wave's operations out in order)
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                const float4* const mine = (const float4*)&s_b[0][0] + 4u * (t & 192u); // the wave's 64 records
+                float4* const out = (float4*)nodes + 4 * (size_t)(i - lane);
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t piece = j * 64u + lane; // 16-byte piece of the wave's 4 KiB: record piece / 4
+                    if ((mm >> (piece >> 2)) & 1ull) out[piece] = mine[piece];
+                }
+            }
+            __syncthreads();
+        }
+    }
     // The tops, in leaf order: the lane that carried a subtree to where it stopped holds it, and the lanes' own leaves
     // lie in their subtrees, so the order of the lanes is the order of the subtrees.
     const bool top = t < count && exit_gp != -2 && (exit_gp < 0 || exit_gp >= (int)kChunk - 1 || s_flag[exit_gp] != kMerged);
