@@ -621,7 +621,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
                                                          float4* __restrict__ TB, float4* __restrict__ TC,
                                                          uint32_t n, float* __restrict__ union_box, float* __restrict__ nodes,
                                                          float4* __restrict__ tops, uint32_t* __restrict__ top_counts,
-                                                         uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
+                                                         uint32_t top_cap, uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
                                                          uint32_t* __restrict__ finished_count, float* __restrict__ fine,
                                                          uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
     __shared__ float s_b[6][2 * kChunk];  // boxes: [p] of the leaf at p, [kChunk + name] of a node made here
@@ -774,10 +774,10 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
     }
     if (t == 0) {
         top_counts[chunk] = total;
-        if (total > kTopCap) *overflow = 1u;
+        if (total > top_cap) *overflow = 1u;
         if (nmade) atomicAdd(finished_count, nmade);
     }
-    if (top && at < kTopCap) {
+    if (top && at < top_cap) {
         float4* o = tops + 3 * ((size_t)chunk * kTopCap + at);
         o[0] = make_float4(bx[0], bx[1], bx[2], __uint_as_float(base + l));
         o[1] = make_float4(bx[3], bx[4], bx[5], __uint_as_float(base + r));
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
 // and linked its nodes took three times as long: some 400 instructions a trip, issued one wave at a time.)
 // A reference to a child or a top: an item's index, or 0x8000 | the split of a node made here.
 __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __restrict__ tops_in, const uint32_t* __restrict__ counts_in,
-                                                     uint32_t nunits, uint32_t n, float4* __restrict__ tops_out,
+                                                     uint32_t nunits, uint32_t n, uint32_t top_cap, float4* __restrict__ tops_out,
                                                      uint32_t* __restrict__ counts_out, float* __restrict__ union_box, float* __restrict__ nodes,
                                                      uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
                                                      uint32_t* __restrict__ finished_count, float* __restrict__ fine,
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
     const uint32_t u0 = blockIdx.x * kLevelUnits, nu = min(kLevelUnits, nunits - u0);
     static_assert(kLevelUnits <= 64u && kLevelItems <= 0x8000u, "one wave adds up the units' counts; references fit 16 bits");
     if (tid < 64u) {
-        const uint32_t c = tid < nu ? min(counts_in[u0 + tid], kTopCap) : 0u;
+        const uint32_t c = tid < nu ? min(counts_in[u0 + tid], top_cap) : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
             if (w < wave) at += s_wcount[w];
             round += s_wcount[w];
         }
-        if (top && at < kTopCap) {
+        if (top && at < top_cap) {
             const uint32_t ref = e & 0xFFFFu, i = ref & 0x7FFFu;
             const bool nd = (ref & 0x8000u) != 0u;
             const uint32_t il = nd ? s_nit[i] & 0xFFFFu : i, ir = nd ? s_nit[i] >> 16 : i;
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
     const uint32_t nf = min(s_nfine, kLevelFine);
     if (tid == 0) {
         counts_out[blockIdx.x] = before;
-        if (before > kTopCap) *overflow = 1u;
+        if (before > top_cap) *overflow = 1u;
         if (s_made) atomicAdd(finished_count, s_made);
         s_fbase = nf ? atomicAdd(fine_count, nf) : 0u;
     }
@@ -1436,14 +1436,17 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
                            C1, b_child, b_parent, range, n, union_box, sc.nodes, arrive, slots, words + kWRootDone,
                            words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
     } else {
+        // (INV_BUILD_TOP_CAP in the environment: fewer tops per unit than the arrays hold, so that ordinary scenes take the
+        // way of trees too unbalanced for them; for tests)
+        static const uint32_t top_cap = getenv("INV_BUILD_TOP_CAP") ? std::min<uint32_t>(kTopCap, (uint32_t)atoi(getenv("INV_BUILD_TOP_CAP"))) : kTopCap;
         hipLaunchKernelGGL(k_build_chunks, dim3(nchunks), dim3(kChunk), 0, s, T0, mesh, (const uint32_t*)sc.order,
-                           (const uint64_t*)sc.morton, sc.slot_of, A1, B1, C1, n, union_box, sc.nodes, tops[0], top_counts[0], words + kWOverflow, words + kWRootDone,
+                           (const uint64_t*)sc.morton, sc.slot_of, A1, B1, C1, n, union_box, sc.nodes, tops[0], top_counts[0], top_cap, words + kWOverflow, words + kWRootDone,
                            words + kWFinishedChunks, sc.fine, fine_count, fine_cap);
         int in = 0;
         for (uint32_t units = nchunks; units > 1u; in ^= 1) {
             const uint32_t wgs = level_units_for(units);
             hipLaunchKernelGGL(k_build_level, dim3(wgs), dim3(kLevelThreads), 0, s, (const float4*)tops[in], (const uint32_t*)top_counts[in],
-                               units, n, tops[in ^ 1], top_counts[in ^ 1], union_box, sc.nodes,
+                               units, n, top_cap, tops[in ^ 1], top_counts[in ^ 1], union_box, sc.nodes,
                                words + kWOverflow, words + kWRootDone, words + kWFinishedClimb, sc.fine, fine_count, fine_cap);
             units = wgs;
         }

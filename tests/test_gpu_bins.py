@@ -114,7 +114,21 @@ def test_lbvh_suite_with_the_scan_kernel_between_the_sort_kernels():
     """The LBVH structure tests again with INV_SORT_SCAN_KERNEL=1: the second level of the radix sort's scan runs as a
     kernel of its own, as it does for scenes of more than eight million triangles (smaller ones leave it to the scatter
     kernel), here on the scenes of 0.7 and 5 million."""
-    _parity_suite_with(names="lbvh_structure_large or config4 or lbvh_runs", INV_SORT_SCAN_KERNEL="1")
+    _parity_suite_with(names="lbvh_structure_large or config4_1024 or lbvh_runs", INV_SORT_SCAN_KERNEL="1")
+
+
+def test_lbvh_suite_with_the_searching_build():
+    """The LBVH structure tests again with INV_BUILD_SEARCH=1: every node finds its range by T. Karras's searches, the
+    chunks only refit and the nodes across chunk boundaries are climbed through memory (the build before the chunks
+    and the levels above them merged bottom-up; still the way of trees too unbalanced for that): the same trees."""
+    _parity_suite_with(names="lbvh or config4_1024 or tree_deeper or tiny_scenes", INV_BUILD_SEARCH="1")
+
+
+def test_lbvh_suite_when_units_hand_up_more_tops_than_they_may():
+    """INV_BUILD_TOP_CAP=6: a chunk may hand up six unfinished subtrees (ordinary chunks have ten), so the bottom-up
+    build gives up on every scene of more than a chunk and the build starts again the searching way, as it would for
+    a tree too unbalanced for the arrays: the same trees, and scenes of a single chunk never get there."""
+    _parity_suite_with(names="lbvh or config4_1024 or tree_deeper or tiny_scenes", INV_BUILD_TOP_CAP="6")
 
 
 def test_parity_suite_from_the_coarse_cut():
