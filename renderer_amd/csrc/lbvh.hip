@@ -814,6 +814,14 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
     __shared__ float4 s_fine[2 * kLevelFine]; // the fine cut's records made here, written out together at the end
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t u0 = blockIdx.x * kLevelUnits, nu = min(kLevelUnits, nunits - u0);
+    // A unit below that had more tops than it may hand up has handed up some of them only: nothing can be made of
+    // those (names and ranges would come out wrong, and records would be written where none belong).  The build is
+    // then done again the other way; this launch and those after it do nothing.  (One lane reads the flag for all:
+    // another workgroup of this very launch may raise it meanwhile, and the lanes must agree.)
+    __shared__ uint32_t s_stop;
+    if (tid == 0) s_stop = *overflow;
+    __syncthreads();
+    if (s_stop != 0u) return;
     static_assert(kLevelUnits <= 64u && kLevelItems <= 0x8000u, "one wave adds up the units' counts; references fit 16 bits");
     if (tid < 64u) {
         const uint32_t c = tid < nu ? min(counts_in[u0 + tid], top_cap) : 0u;
@@ -900,6 +908,7 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
         const uint32_t gamma = n0 ? s_nr[i0] : s_ir[i0]; // last leaf of the left child
         const bool leaf0 = l == gamma, leaf1 = gamma + 1u == r;
         const uint32_t c0 = gamma | (leaf0 ? 0x80000000u : 0u), c1 = (gamma + 1u) | (leaf1 ? 0x80000000u : 0u);
+        if (me + 1u >= n) continue; // (never with whole input: a name is a leaf with a neighbour on the named side)
         float4* nd = (float4*)nodes + 4 * (size_t)me;
         nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
         nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
@@ -1178,13 +1187,15 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
                                                           float* __restrict__ groups,
                                                           const uint32_t* __restrict__ root_done,
                                                           const uint32_t* __restrict__ unsorted,
+                                                          const uint32_t* __restrict__ overflow,
                                                           const float* __restrict__ bbox,
                                                           const float* __restrict__ union_box,
                                                           uint32_t* __restrict__ summary) {
     __shared__ uint32_t frontier[2][kCutCap]; // (parent << 1) | side
     __shared__ uint32_t tot[2][kCutThreads / 64];
     const uint32_t tid = threadIdx.x;
-    if (*root_done == 0u || *unsorted != 0u) { // block-uniform (unsorted: the sort gave up, the tree is not to be read)
+    // block-uniform (unsorted: the sort gave up; overflow: the bottom-up build gave up: the tree is not to be read)
+    if (*root_done == 0u || *unsorted != 0u || *overflow != 0u) {
         if (tid == 0) summary[0] = kCutUnfinished;
         return;
     }
@@ -1465,7 +1476,8 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
                                union_box, sc.nodes, words + kWFinishedClimb, words + kWRootDone, sc.fine, fine_count, fine_cap);
     }
     hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
-                       (const uint32_t*)(words + kWRootDone), (const uint32_t*)too_long, (const float*)d_bbox,
+                       (const uint32_t*)(words + kWRootDone), (const uint32_t*)too_long, (const uint32_t*)(words + kWOverflow),
+                       (const float*)d_bbox,
                        (const float*)union_box, words + kWSummary);
     HIP_RET(hipGetLastError());
     uint32_t host_words[kWords] = {0};
