@@ -288,7 +288,7 @@ def main():
                          "from close by) that follow the timed region and show where sharding pays")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on one GPU (ranks share cuda:0, gather through host memory)")
-    ap.add_argument("--watchdog-seconds", type=int, default=1500,
+    ap.add_argument("--watchdog-seconds", type=int, default=900,
                     help="a rank still running after this long writes every thread's Python stack to standard error and "
                          "exits with a failure, so that a collective that never completes ends the run with a message "
                          "instead of hanging it (0: off)")

@@ -67,27 +67,40 @@ __device__ __forceinline__ uint32_t grid21(float c, float lo, float ext) {
 
 // The record comes from memory, or -- with `mesh` -- is assembled again from a mesh that the caches hold (the same
 // floats: assemble_record), which saves reading 48 bytes per triangle.
+// A workgroup makes the keys of one tile of the sort (kSortTile triangles) and counts their digits of the sort's first
+// pass on the way: that pass then needs no histogram kernel of its own (`counts` as k_sort_hist leaves them).
 __global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, MeshSource mesh, uint32_t n,
                                                 const float* __restrict__ bbox, uint64_t* __restrict__ keys,
-                                                uint32_t* __restrict__ vals) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 ra, rb, rc;
-    if (mesh.xyzw) { // (the same for every lane)
-        assemble_record(mesh, i, ra, rb, rc);
-    } else {
-        ra = T[3 * (size_t)i], rb = T[3 * (size_t)i + 1], rc = T[3 * (size_t)i + 2];
-    }
-    float lo[3], hi[3];
-    tri_box(ra, rb, rc, lo, hi);
+                                                uint32_t* __restrict__ vals, int shift, uint32_t ntiles,
+                                                uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
     // one grid step for all three axes (the largest extent): cubic cells, whatever the shape of the scene -- with a
     // step per axis a flat scene (a grid of instances in a plane) gets cells that are thin slabs, and consecutive keys
     // then walk around an instance instead of across a patch of its surface
-    float ex = fmaxf(bbox[3] - bbox[0], fmaxf(bbox[4] - bbox[1], bbox[5] - bbox[2])), ey = ex, ez = ex;
-    float cx = (lo[0] + hi[0]) * 0.5f, cy = (lo[1] + hi[1]) * 0.5f, cz = (lo[2] + hi[2]) * 0.5f;
-    keys[i] = (expand21(grid21(cx, bbox[0], ex)) << 2) | (expand21(grid21(cy, bbox[1], ey)) << 1) |
-              expand21(grid21(cz, bbox[2], ez));
-    vals[i] = i;
+    const float ex = fmaxf(bbox[3] - bbox[0], fmaxf(bbox[4] - bbox[1], bbox[5] - bbox[2]));
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t r = 0; r < 8u; r++) {
+        const uint32_t i = tile * 2048u + r * 256u + threadIdx.x;
+        if (i >= n) break;
+        float4 ra, rb, rc;
+        if (mesh.xyzw) { // (the same for every lane)
+            assemble_record(mesh, i, ra, rb, rc);
+        } else {
+            ra = T[3 * (size_t)i], rb = T[3 * (size_t)i + 1], rc = T[3 * (size_t)i + 2];
+        }
+        float lo[3], hi[3];
+        tri_box(ra, rb, rc, lo, hi);
+        const float cx = (lo[0] + hi[0]) * 0.5f, cy = (lo[1] + hi[1]) * 0.5f, cz = (lo[2] + hi[2]) * 0.5f;
+        const uint64_t key = (expand21(grid21(cx, bbox[0], ex)) << 2) | (expand21(grid21(cy, bbox[1], ex)) << 1) |
+                             expand21(grid21(cz, bbox[2], ex));
+        keys[i] = key;
+        vals[i] = i;
+        atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[threadIdx.x * ntiles + tile] = hist[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1410,10 +1423,12 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     uint32_t* vin = (steps & 1) ? vals_alt : sc.order;
     uint64_t* kout = (steps & 1) ? sc.morton : keys_alt;
     uint32_t* vout = (steps & 1) ? sc.order : vals_alt;
-    hipLaunchKernelGGL(k_morton, grid_n, blk, 0, s, T0, mesh, n, d_bbox, kin, vin);
+    static_assert(kSortTile == 2048 && kSortThreads == 256, "k_morton counts the digits of one sort tile per workgroup");
+    hipLaunchKernelGGL(k_morton, dim3(ntiles), blk, 0, s, T0, mesh, n, d_bbox, kin, vin, sort_shift, ntiles, counts);
     for (int pass = sort_shift / 8; pass < 8; pass++) {
         const int shift = 8 * pass;
-        hipLaunchKernelGGL(k_sort_hist, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
+        if (pass != sort_shift / 8) // (the first pass's digits were counted with the keys)
+            hipLaunchKernelGGL(k_sort_hist, dim3(xcd_grid(ntiles)), dim3(kSortThreads), 0, s, kin, n, shift, ntiles, counts);
         const uint32_t ncount = ntiles * 256u;
         uint32_t raw_blocks = 0;
         if (ncount <= 16384u) {
