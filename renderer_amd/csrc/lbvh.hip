@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, Me
     // then walk around an instance instead of across a patch of its surface
     const float ex = fmaxf(bbox[3] - bbox[0], fmaxf(bbox[4] - bbox[1], bbox[5] - bbox[2]));
     const uint32_t tile = blockIdx.x;
-    for (uint32_t r = 0; r < 8u; r++) {
-        const uint32_t i = tile * 2048u + r * 256u + threadIdx.x;
+    for (uint32_t r = 0; r < (uint32_t)kSortItems; r++) {
+        const uint32_t i = tile * (uint32_t)kSortTile + r * 256u + threadIdx.x;
         if (i >= n) break;
         float4 ra, rb, rc;
         if (mesh.xyzw) { // (the same for every lane)
@@ -615,6 +615,49 @@ __global__ __launch_bounds__(kChunk) void k_refit_chunks(const float4* __restric
 //     further launches for five million triangles, no node ever searching or waiting for anything in memory.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kMerged = 0xFFFFFFFFu;
+typedef float v4f __attribute__((ext_vector_type(4)));
+// min and max of box coordinates as single instructions (fminf and fmaxf first turn each operand into its canonical form,
+// an instruction each, which changes nothing for the numbers boxes are made of)
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Put the 32 bytes m0, m1 at `mine`, swap `word` into *flag and read the 32 bytes at `slot` behind it, all in LDS (the
+// slots 16-byte aligned), without waiting for the swap's answer in between: returns what the flag held.  Written out
+// because the order of the five is the point -- left to itself the compiler moves the reads to where their values are
+// used, behind the wait for the answer.  (The low half of an LDS pointer is the offset the instructions take.)
+__device__ __forceinline__ uint32_t lds_put_swap_then_read(float4* mine, v4f m0, v4f m1, uint32_t* flag, uint32_t word, const float4* slot,
+                                                           v4f& s0, v4f& s1) {
+    uint32_t other;
+    const uint32_t ma = (uint32_t)(uintptr_t)mine, fa = (uint32_t)(uintptr_t)flag, sa = (uint32_t)(uintptr_t)slot;
+    asm volatile("ds_write_b128 %6, %7\n\tds_write_b128 %6, %8 offset:16\n\tds_wrxchg_rtn_b32 %0, %3, %4\n\tds_read_b128 %1, %5\n\t"
+                 "ds_read_b128 %2, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(other), "=&v"(s0), "=&v"(s1)
+                 : "v"(fa), "v"(word), "v"(sa), "v"(ma), "v"(m0), "v"(m1)
+                 : "memory");
+    return other;
+}
+// (the same with four more bytes of one's own, `mw` to `mine_w`, and of the sibling's, from `word_at`)
+__device__ __forceinline__ uint32_t lds_put_swap_then_read(float4* mine, v4f m0, v4f m1, uint32_t* mine_w, uint32_t mw, uint32_t* flag,
+                                                           uint32_t word, const float4* slot, const uint32_t* word_at, v4f& s0,
+                                                           v4f& s1, uint32_t& w) {
+    uint32_t other;
+    const uint32_t ma = (uint32_t)(uintptr_t)mine, mwa = (uint32_t)(uintptr_t)mine_w, fa = (uint32_t)(uintptr_t)flag,
+                   sa = (uint32_t)(uintptr_t)slot, wa = (uint32_t)(uintptr_t)word_at;
+    asm volatile("ds_write_b128 %8, %9\n\tds_write_b128 %8, %10 offset:16\n\tds_write_b32 %11, %12\n\tds_wrxchg_rtn_b32 %0, %4, %5\n\t"
+                 "ds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(other), "=&v"(s0), "=&v"(s1), "=&v"(w)
+                 : "v"(fa), "v"(word), "v"(sa), "v"(wa), "v"(ma), "v"(m0), "v"(m1), "v"(mwa), "v"(mw)
+                 : "memory");
+    return other;
+}
 constexpr uint32_t kTopCap = 64;       // tops a unit may hand up (more: the build starts again the other way)
 constexpr uint32_t kLevelUnits = 32;   // units whose tops one workgroup of k_build_level merges
 constexpr uint32_t kLevelItems = 768;  // tops it can hold (32 units hand up some 400; two such workgroups share a CU's LDS)
@@ -637,13 +680,17 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
                                                          uint32_t top_cap, uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
                                                          uint32_t* __restrict__ finished_count, float* __restrict__ fine,
                                                          uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
-    __shared__ float s_b[6][2 * kChunk];  // boxes: [p] of the leaf at p, [kChunk + name] of a node made here
-    __shared__ uint64_t s_key[kChunk + 2]; // keys of the chunk and of one leaf on either side
+    // per split g (between the chunk's leaves g and g + 1) the two subtrees that meet there, as they arrive: [2 g] the one
+    // that ends at g, [2 g + 1] the one that begins at g + 1; (box lo, height) (box hi, -)
+    __shared__ float4 s_slot[2 * kChunk][2];
+    // first the keys of the chunk and of one leaf on either side; then, in the same place, per split: s_flag (0, or what
+    // the first child to arrive left: its far end + 1 | the prefix beyond that end + 1 << 16, or kMerged) and, per node
+    // made here, by name: s_info (1 << 31 | r << 18 | l << 9 | split)
+    __shared__ uint64_t s_key[kChunk + 2];
     __shared__ int s_delta[kChunk + 1];   // [p + 1]: common prefix of the keys at p and p + 1, p = -1 .. kChunk - 1; -1: no such leaf
-    __shared__ uint32_t s_flag[kChunk];   // per split g (between g and g + 1): 0, or the first child's far end + 1, or kMerged
-    __shared__ uint32_t s_info[kChunk];   // per node made here, by name: 1 << 31 | r << 18 | l << 9 | split
-    __shared__ uint32_t s_height[kChunk];
     __shared__ uint32_t s_wcount[kChunk / 64], s_wmade[kChunk / 64];
+    uint32_t* const s_flag = (uint32_t*)s_key;
+    uint32_t* const s_info = s_flag + kChunk;
     const uint32_t chunk = blockIdx.x, t = threadIdx.x, base = chunk * kChunk, i = base + t;
     const uint32_t count = min(kChunk, n - base); // leaves of this chunk
     const uint32_t src = i < n ? order[i] : 0u;
@@ -665,9 +712,8 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         float lo[3], hi[3];
         tri_box(a, b, c, lo, hi);
 #pragma unroll
-        for (int a = 0; a < 3; a++) s_b[a][t] = bx[a] = lo[a], s_b[3 + a][t] = bx[3 + a] = hi[a];
+        for (int a = 0; a < 3; a++) bx[a] = lo[a], bx[3 + a] = hi[a];
     }
-    s_flag[t] = 0u, s_info[t] = 0u, s_height[t] = 0u;
     __syncthreads();
     {
         // boundary between local positions t and t + 1 (and, by lane 0, between -1 and 0)
@@ -675,47 +721,44 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         s_delta[t + 1] = have ? key_delta(s_key[t + 1], s_key[t + 2], i, i + 1u) : -1;
         if (t == 0) s_delta[0] = base ? key_delta(s_key[0], s_key[1], base - 1u, base) : -1;
     }
+    __syncthreads(); // the keys have been read: their place is the flags' and the names' now
+    s_flag[t] = 0u, s_info[t] = 0u;
     __syncthreads();
-    uint32_t l = t, r = t, h = 0;
+    uint32_t l = t, r = t;
+    v4f lo4 = {bx[0], bx[1], bx[2], 0.0f}, hi4 = {bx[3], bx[4], bx[5], 0.0f}; // the box of [l, r]; lo4.w: the height's bits
+    int dl = s_delta[t], dr = s_delta[t + 1]; // the prefixes beyond the two ends of [l, r]
     int exit_gp = -2; // the split this lane's subtree waits at; -1 or kChunk - 1: a chunk boundary; -2: no subtree (or the root)
     {
-        uint32_t split = 0;
+        // A trip of this loop is one exchange with LDS.  A wave's LDS operations are carried out in the order it issues
+        // them, and LDS carries out one at a time: a subtree puts its box in its slot, swaps its far end into the flag and
+        // reads the sibling's slot without waiting to learn whether the sibling has been -- if the flag was not empty,
+        // the sibling's box went in before the sibling's swap, this swap came after that and the read after this swap.
+        // (The compiler must keep that order; a fence of the memory model would also wait for the stores to global
+        // memory still in flight.)  The first to arrive stops; the second has the parent's box, leaves, height and, from
+        // the flag, the prefix beyond the new end, which tells it the parent's name and where the parent goes next.
         bool alive = t < count;
         while (alive) {
-            const int dl = s_delta[l], dr = s_delta[r + 1];
-            const bool whole = dl < 0 && dr < 0; // the root, all in this chunk
+            if (dl < 0 && dr < 0) break; // the root, all in this chunk
             const bool right = dr > dl;
-            if (l < r) { // a node made in the previous trip: now it has a name
-                const uint32_t me = whole ? 0u : right ? r : l;
-#pragma unroll
-                for (int a = 0; a < 6; a++) s_b[a][kChunk + me] = bx[a];
-                s_height[me] = h;
-                s_info[me] = 0x80000000u | (r << 18) | (l << 9) | split;
-            }
-            if (whole) break;
             const int gp = right ? (int)r : (int)l - 1; // the parent's split
             exit_gp = gp;
             if (gp < 0 || gp >= (int)kChunk - 1) break; // the sibling lies in another chunk
-            // (Everything the two children exchange is in LDS, and a wave's LDS operations are carried out in the order
-            // it issues them: the box is in place before the flag, and read after it.  The compiler must keep that
-            // order; a fence of the memory model would also wait for the stores to global memory still in flight.)
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            const uint32_t other = atomicExch(&s_flag[gp], (right ? l : r) + 1u);
+            const uint32_t mine = 2u * (uint32_t)gp + (right ? 0u : 1u);
+            v4f s0, s1;
+            const uint32_t other = lds_put_swap_then_read(&s_slot[mine][0], lo4, hi4, &s_flag[gp],
+                                                          ((right ? l : r) + 1u) | ((uint32_t)((right ? dl : dr) + 1) << 16),
+                                                          &s_slot[mine ^ 1u][0], s0, s1);
             if (other == 0u) break; // the first to arrive
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            const uint32_t far = other - 1u;
-            const uint32_t sib = right ? (uint32_t)gp + 1u : (uint32_t)gp; // the sibling's name (or position, for a leaf)
-            const bool sib_leaf = right ? far == sib : far == sib;
-            float sb[6];
-            const uint32_t sat = sib_leaf ? sib : kChunk + sib;
-#pragma unroll
-            for (int a = 0; a < 6; a++) sb[a] = s_b[a][sat];
-            const uint32_t sh = sib_leaf ? 0u : s_height[sib];
-#pragma unroll
-            for (int a = 0; a < 3; a++) bx[a] = fminf(bx[a], sb[a]), bx[3 + a] = fmaxf(bx[3 + a], sb[3 + a]);
-            h = 1u + (h > sh ? h : sh);
-            if (right) r = far; else l = far;
-            split = (uint32_t)gp;
+            lo4.x = min_raw(lo4.x, s0.x), lo4.y = min_raw(lo4.y, s0.y), lo4.z = min_raw(lo4.z, s0.z);
+            hi4.x = max_raw(hi4.x, s1.x), hi4.y = max_raw(hi4.y, s1.y), hi4.z = max_raw(hi4.z, s1.z);
+            const uint32_t h = __float_as_uint(lo4.w), sh = __float_as_uint(s0.w);
+            lo4.w = __uint_as_float(1u + (h > sh ? h : sh));
+            const uint32_t far = (other & 0xFFFFu) - 1u;
+            const int dfar = (int)(other >> 16) - 1;
+            if (right) r = far, dr = dfar; else l = far, dl = dfar;
+            // the node just made, under its name (a left child is named after its last leaf, a right child after its first)
+            const uint32_t me = (dl < 0 && dr < 0) ? 0u : dr > dl ? r : l;
+            s_info[me] = 0x80000000u | (r << 18) | (l << 9) | (uint32_t)gp;
             s_flag[gp] = kMerged;
             exit_gp = -2;
         }
@@ -734,43 +777,39 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         const bool leaf0 = l == g, leaf1 = g + 1u == r;
         c0 = (base + g) | (leaf0 ? 0x80000000u : 0u), c1 = (base + g + 1u) | (leaf1 ? 0x80000000u : 0u);
         leaves = make_uint2(base + l, base + r);
-#pragma unroll
-        for (int a = 0; a < 6; a++) b0[a] = s_b[a][leaf0 ? g : kChunk + g], b1[a] = s_b[a][leaf1 ? g + 1u : kChunk + g + 1u];
         // (the record -- written below -- is all of the node there is: who asks for child or parent arrays gets them made
         // from the records)
+        const float4 p0 = s_slot[2u * g][0], p1 = s_slot[2u * g][1], q0 = s_slot[2u * g + 1u][0], q1 = s_slot[2u * g + 1u][1];
+        b0[0] = p0.x, b0[1] = p0.y, b0[2] = p0.z, b0[3] = p1.x, b0[4] = p1.y, b0[5] = p1.z;
+        b1[0] = q0.x, b1[1] = q0.y, b1[2] = q0.z, b1[3] = q1.x, b1[4] = q1.y, b1[5] = q1.z;
         if (s_delta[l] < 0 && s_delta[r + 1u] < 0) { // the root: one chunk holds it all
             float4* ub = (float4*)union_box; // (its box and height, for the build's summary)
-            ub[0] = make_float4(s_b[0][kChunk + t], s_b[1][kChunk + t], s_b[2][kChunk + t], s_b[3][kChunk + t]);
-            ub[1] = make_float4(s_b[4][kChunk + t], s_b[5][kChunk + t], __uint_as_float(s_height[t]), 0.0f);
+            const uint32_t h0 = __float_as_uint(p0.w), h1 = __float_as_uint(q0.w);
+            ub[0] = make_float4(fminf(b0[0], b1[0]), fminf(b0[1], b1[1]), fminf(b0[2], b1[2]), fmaxf(b0[3], b1[3]));
+            ub[1] = make_float4(fmaxf(b0[4], b1[4]), fmaxf(b0[5], b1[5]), __uint_as_float(1u + (h0 > h1 ? h0 : h1)), 0.0f);
             *root_done = 1u;
         }
     }
     emit_fine<(int)kChunk>(made, c0, leaves, b0, b1, fine, fine_count, fine_cap);
     // The records of the nodes made here.  A lane that stored its own 64 bytes would make every store instruction of
-    // the wave touch 64 different lines, 16 bytes of each; through LDS (the boxes' array, which nobody reads any more:
-    // emit_fine ended with a barrier) a wave's records leave as four instructions of 1 KiB of consecutive bytes each.
-    // Half of the waves at a time: the array holds 256 records.
+    // the wave touch 64 different lines, 16 bytes of each; through LDS (the slots' array, which nobody reads any more:
+    // emit_fine's barriers lie in between) a wave's records leave as four instructions of 1 KiB of consecutive bytes each.
     {
-        float4* const stage = (float4*)&s_b[0][0] + 4u * (t & 255u); // this lane's record
+        float4* const stage = (float4*)&s_slot[0][0] + 4u * t; // this lane's record
         const uint32_t lane = t & 63u;
         const uint64_t mm = __ballot(made);
-        for (uint32_t half = 0; half < 2u; half++) { // block-uniform
-            if ((t >> 8) == half) {
-                stage[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
-                stage[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
-                stage[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
-                stage[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
-                // (a wave reads only what it wrote itself, and LDS carries a wave's operations out in order)
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                const float4* const mine = (const float4*)&s_b[0][0] + 4u * (t & 192u); // the wave's 64 records
-                float4* const out = (float4*)nodes + 4 * (size_t)(i - lane);
+        stage[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+        stage[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+        stage[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+        stage[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
+        // (a wave reads only what it wrote itself, and LDS carries a wave's operations out in order)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const float4* const mine = (const float4*)&s_slot[0][0] + 4u * (t - lane); // the wave's 64 records
+        float4* const out = (float4*)nodes + 4 * (size_t)(i - lane);
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    const uint32_t piece = j * 64u + lane; // 16-byte piece of the wave's 4 KiB: record piece / 4
-                    if ((mm >> (piece >> 2)) & 1ull) out[piece] = mine[piece];
-                }
-            }
-            __syncthreads();
+        for (uint32_t j = 0; j < 4u; j++) {
+            const uint32_t piece = j * 64u + lane; // 16-byte piece of the wave's 4 KiB: record piece / 4
+            if ((mm >> (piece >> 2)) & 1ull) out[piece] = mine[piece];
         }
     }
     // The tops, in leaf order: the lane that carried a subtree to where it stopped holds it, and the lanes' own leaves
@@ -792,37 +831,33 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
     }
     if (top && at < top_cap) {
         float4* o = tops + 3 * ((size_t)chunk * kTopCap + at);
-        o[0] = make_float4(bx[0], bx[1], bx[2], __uint_as_float(base + l));
-        o[1] = make_float4(bx[3], bx[4], bx[5], __uint_as_float(base + r));
-        o[2] = make_float4(__uint_as_float((uint32_t)(s_delta[l] + 1) | ((uint32_t)(s_delta[r + 1u] + 1) << 8) | (h << 16)), 0.0f, 0.0f, 0.0f);
+        o[0] = make_float4(lo4.x, lo4.y, lo4.z, __uint_as_float(base + l));
+        o[1] = make_float4(hi4.x, hi4.y, hi4.z, __uint_as_float(base + r));
+        o[2] = make_float4(__uint_as_float((uint32_t)(dl + 1) | ((uint32_t)(dr + 1) << 8) | (__float_as_uint(lo4.w) << 16)), 0.0f, 0.0f, 0.0f);
     }
 }
 
 // The same merging one level up: a workgroup takes the tops of kLevelUnits consecutive units (chunks, or workgroups of
-// the level below) as its items, in leaf order, and hands up its own tops.  A lane carries one item at a time; nobody
-// waits for anybody (the second child to arrive at a split goes on, the first stops), so a lane can carry several one
-// after the other.  The time of such a workgroup is the longest chain of merges from an item to the top, one lane
-// busy, so the loop does the least it can: it leaves every node it makes in LDS, under the node's split (box, leaves,
-// children, name), and a lane per node writes the records to memory afterwards.  (A loop that also named, recorded
-// and linked its nodes took three times as long: some 400 instructions a trip, issued one wave at a time.)
-// A reference to a child or a top: an item's index, or 0x8000 | the split of a node made here.
+// the level below) as its items, in leaf order, a lane each, and hands up its own tops.  Nobody waits for anybody (the
+// second child to arrive at a split goes on, the first stops).  The time of such a workgroup is the longest chain of
+// merges from an item to the top, one lane busy, so a trip of the loop does the least it can: the subtree leaves what
+// its parent's record will say of it (box, leaves, height) in its slot at the parent's split, swaps, reads the
+// sibling's slot; whoever goes on names the parent.  A lane per split writes the records to memory afterwards, from
+// the two slots.  (A loop that also recorded and linked its nodes took three times as long: some 400 instructions a
+// trip, issued one wave at a time; one that waited for LDS three times a trip, twice as long as this.)
 __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __restrict__ tops_in, const uint32_t* __restrict__ counts_in,
                                                      uint32_t nunits, uint32_t n, uint32_t top_cap, float4* __restrict__ tops_out,
                                                      uint32_t* __restrict__ counts_out, float* __restrict__ union_box, float* __restrict__ nodes,
                                                      uint32_t* __restrict__ overflow, uint32_t* __restrict__ root_done,
                                                      uint32_t* __restrict__ finished_count, float* __restrict__ fine,
                                                      uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
-    // (gfx950 lets one workgroup have all 160 KiB of a CU's LDS; these workgroups are few and run one per CU)
-    __shared__ float s_ibox[6][kLevelItems];  // the items: box, first and last leaf, height
-    __shared__ uint32_t s_il[kLevelItems], s_ir[kLevelItems], s_ih[kLevelItems];
-    __shared__ float s_nbox[6][kLevelItems];  // the nodes made here, by split: box, first and last leaf, height,
-    __shared__ uint32_t s_nl[kLevelItems], s_nr[kLevelItems], s_nh[kLevelItems]; // ...
-    __shared__ uint32_t s_nch[kLevelItems];   // ... left child | right child << 16 (references),
-    __shared__ uint32_t s_nit[kLevelItems];   // ... first item | last item << 16,
-    __shared__ uint32_t s_nme[kLevelItems];   // ... and name
-    __shared__ int s_delta[kLevelItems + 1];  // [k + 1]: prefix between items k and k + 1; [0], [M]: at the ends
-    __shared__ uint32_t s_flag[kLevelItems];  // per split: 0, or (far item | reference << 16) + 1 of the first child, or kMerged
-    __shared__ uint32_t s_exit[kLevelItems];  // per carried item: reference | (split it waits at + 1) << 16; 0xFFFFFFFF: nothing left
+    // per split g (between items g and g + 1) the two subtrees that meet there, as they arrive: [2 g] the one that ends
+    // with item g, [2 g + 1] the one that begins with item g + 1; (box lo, first leaf) (box hi, last leaf), and the height
+    __shared__ float4 s_slot[2 * kLevelItems][2];
+    __shared__ uint32_t s_sh[2 * kLevelItems];
+    __shared__ uint32_t s_nme[kLevelItems];   // per split: the name of the node made there
+    // per split: 0, or what the first child to arrive left (its far item + 1 | the prefix beyond that end + 1 << 10), or kMerged
+    __shared__ uint32_t s_flag[kLevelItems];
     __shared__ uint32_t s_off[kLevelUnits + 1], s_wcount[kLevelThreads / 64], s_made, s_nfine, s_fbase;
     __shared__ float4 s_fine[2 * kLevelFine]; // the fine cut's records made here, written out together at the end
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -835,7 +870,8 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
     if (tid == 0) s_stop = *overflow;
     __syncthreads();
     if (s_stop != 0u) return;
-    static_assert(kLevelUnits <= 64u && kLevelItems <= 0x8000u, "one wave adds up the units' counts; references fit 16 bits");
+    static_assert(kLevelUnits <= 64u && kLevelItems <= kLevelThreads && kLevelItems <= 1023u,
+                  "one wave adds up the units' counts; a lane per item; an item's index + 1 fits ten bits of the flag");
     if (tid < 64u) {
         const uint32_t c = tid < nu ? min(counts_in[u0 + tid], top_cap) : 0u;
         uint32_t incl = c;
@@ -848,155 +884,135 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
         if (tid == nu - 1u) s_off[nu] = incl;
         if (tid == 0) s_made = 0u, s_nfine = 0u;
     }
+    if (tid < kLevelItems) s_flag[tid] = 0u;
     __syncthreads();
     const uint32_t M = s_off[nu];
     if (M > kLevelItems) { // block-uniform: more tops than fit (a very unbalanced tree)
         if (tid == 0) *overflow = 1u, counts_out[blockIdx.x] = 0u;
         return;
     }
-    for (uint32_t k = tid; k < M; k += kLevelThreads) {
+    // Lane k carries item k: the subtree it is part of, as far as this lane takes it, is in registers.
+    const uint32_t k = tid;
+    uint32_t il = k, ir = k, h = 0;              // items of the subtree, its height
+    v4f lo4 = {0, 0, 0, 0}, hi4 = {0, 0, 0, 0};  // its box; lo4.w, hi4.w: the bits of its first and last leaf
+    int dl = -1, dr = -1;                        // the prefixes beyond its two ends
+    int exit_gp = -2; // the split the subtree waits at; outside [0, M - 2]: the sibling is another workgroup's; -2: no subtree, or the root
+    if (k < M) {
         uint32_t u = 0;
         while (s_off[u + 1u] <= k) u++;
         const float4* it = tops_in + 3 * ((size_t)(u0 + u) * kTopCap + (k - s_off[u]));
         const float4 a = it[0], b = it[1], c = it[2];
-        s_ibox[0][k] = a.x, s_ibox[1][k] = a.y, s_ibox[2][k] = a.z, s_ibox[3][k] = b.x, s_ibox[4][k] = b.y, s_ibox[5][k] = b.z;
-        s_il[k] = __float_as_uint(a.w), s_ir[k] = __float_as_uint(b.w);
+        lo4 = (v4f){a.x, a.y, a.z, a.w}, hi4 = (v4f){b.x, b.y, b.z, b.w};
         const uint32_t w = __float_as_uint(c.x);
-        s_ih[k] = w >> 16, s_flag[k] = 0u;
-        s_delta[k + 1u] = (int)((w >> 8) & 255u) - 1;
-        if (k == 0) s_delta[0] = (int)(w & 255u) - 1;
-    }
-    __syncthreads();
-    for (uint32_t k = tid; k < M; k += kLevelThreads) {
-        uint32_t il = k, ir = k, l = s_il[k], r = s_ir[k], h = s_ih[k], ref = k, exit = 0xFFFFFFFFu;
-        float bx[6];
-#pragma unroll
-        for (int a = 0; a < 6; a++) bx[a] = s_ibox[a][k];
+        h = w >> 16;
+        dl = (int)(w & 255u) - 1, dr = (int)((w >> 8) & 255u) - 1;
+        // (one exchange with LDS a trip: see k_build_chunks)
         for (;;) {
-            const int dl = s_delta[il], dr = s_delta[ir + 1u];
-            const bool whole = dl < 0 && dr < 0; // the root
+            if (dl < 0 && dr < 0) break; // the root
             const bool right = dr > dl;
-            if (ref & 0x8000u) s_nme[ref & 0x7FFFu] = whole ? 0u : right ? r : l; // the node made in the previous trip gets its name
-            if (whole) break;
             const int gp = right ? (int)ir : (int)il - 1; // the parent's split, in items
-            exit = ref | ((uint32_t)(gp + 1) << 16);
+            exit_gp = gp;
             if (gp < 0 || gp >= (int)M - 1) break; // the sibling lies in another workgroup's units
-            __atomic_signal_fence(__ATOMIC_SEQ_CST); // (LDS only: see k_build_chunks)
-            const uint32_t other = atomicExch(&s_flag[gp], ((right ? il : ir) | (ref << 16)) + 1u);
+            const uint32_t mine = 2u * (uint32_t)gp + (right ? 0u : 1u);
+            v4f s0, s1;
+            uint32_t sh;
+            const uint32_t other = lds_put_swap_then_read(&s_slot[mine][0], lo4, hi4, &s_sh[mine], h, &s_flag[gp],
+                                                          ((right ? il : ir) + 1u) | ((uint32_t)((right ? dl : dr) + 1) << 10),
+                                                          &s_slot[mine ^ 1u][0], &s_sh[mine ^ 1u], s0, s1, sh);
             if (other == 0u) break; // the first to arrive
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            const uint32_t far = (other - 1u) & 0xFFFFu, sref = (other - 1u) >> 16, si = sref & 0x7FFFu;
-            const bool snode = (sref & 0x8000u) != 0u;
-            float sb[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++) sb[a] = snode ? s_nbox[a][si] : s_ibox[a][si];
-            const uint32_t sl = snode ? s_nl[si] : s_il[si], sr = snode ? s_nr[si] : s_ir[si], sh = snode ? s_nh[si] : s_ih[si];
-#pragma unroll
-            for (int a = 0; a < 3; a++) bx[a] = fminf(bx[a], sb[a]), bx[3 + a] = fmaxf(bx[3 + a], sb[3 + a]);
+            lo4.x = min_raw(lo4.x, s0.x), lo4.y = min_raw(lo4.y, s0.y), lo4.z = min_raw(lo4.z, s0.z);
+            hi4.x = max_raw(hi4.x, s1.x), hi4.y = max_raw(hi4.y, s1.y), hi4.z = max_raw(hi4.z, s1.z);
             h = 1u + (h > sh ? h : sh);
-            if (right) r = sr, ir = far; else l = sl, il = far;
-            const uint32_t g = (uint32_t)gp;
-#pragma unroll
-            for (int a = 0; a < 6; a++) s_nbox[a][g] = bx[a];
-            s_nl[g] = l, s_nr[g] = r, s_nh[g] = h, s_nit[g] = il | (ir << 16);
-            s_nch[g] = right ? (ref | (sref << 16)) : (sref | (ref << 16));
-            ref = 0x8000u | g;
-            s_flag[g] = kMerged;
-            exit = 0xFFFFFFFFu;
+            const uint32_t far = (other & 1023u) - 1u;
+            const int dfar = (int)((other >> 10) & 127u) - 1;
+            hi4.w = right ? s1.w : hi4.w, lo4.w = right ? lo4.w : s0.w; // (selects: no branches)
+            ir = right ? far : ir, il = right ? il : far;
+            dr = right ? dfar : dr, dl = right ? dl : dfar;
+            // the node just made gets its name (a left child is named after its last leaf, a right child after its first)
+            s_nme[gp] = __float_as_uint((dl < 0 && dr < 0) ? 0.0f : dr > dl ? hi4.w : lo4.w);
+            s_flag[gp] = kMerged;
+            exit_gp = -2;
         }
-        s_exit[k] = exit;
     }
     __syncthreads();
-    // every node made here, a lane each: its record, its links, the fine cut's records of its small children
+    // every node made here, a lane each: its record, its links, the fine cut's records of its small children.  What the
+    // two children left in the split's slots is all there is to know about them.
     uint32_t made = 0;
-    for (uint32_t g = tid; g + 1u < M; g += kLevelThreads) {
-        if (s_flag[g] != kMerged) continue;
-        made++;
-        const uint32_t me = s_nme[g], l = s_nl[g], r = s_nr[g], ch = s_nch[g];
-        const uint32_t r0 = ch & 0xFFFFu, r1 = ch >> 16, i0 = r0 & 0x7FFFu, i1 = r1 & 0x7FFFu;
-        const bool n0 = (r0 & 0x8000u) != 0u, n1 = (r1 & 0x8000u) != 0u;
-        float b0[6], b1[6];
-#pragma unroll
-        for (int a = 0; a < 6; a++) b0[a] = n0 ? s_nbox[a][i0] : s_ibox[a][i0], b1[a] = n1 ? s_nbox[a][i1] : s_ibox[a][i1];
-        const uint32_t gamma = n0 ? s_nr[i0] : s_ir[i0]; // last leaf of the left child
-        const bool leaf0 = l == gamma, leaf1 = gamma + 1u == r;
-        const uint32_t c0 = gamma | (leaf0 ? 0x80000000u : 0u), c1 = (gamma + 1u) | (leaf1 ? 0x80000000u : 0u);
-        if (me + 1u >= n) continue; // (never with whole input: a name is a leaf with a neighbour on the named side)
-        float4* nd = (float4*)nodes + 4 * (size_t)me;
-        nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
-        nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
-        nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
-        nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(l), __uint_as_float(r));
-        if (l == 0u && r == n - 1u) { // the root: its box and height, for the build's summary
-            float4* ub = (float4*)union_box;
-            ub[0] = make_float4(s_nbox[0][g], s_nbox[1][g], s_nbox[2][g], s_nbox[3][g]);
-            ub[1] = make_float4(s_nbox[4][g], s_nbox[5][g], __uint_as_float(s_nh[g]), 0.0f);
-            *root_done = 1u;
-        }
-        const uint32_t c0n = gamma - l + 1u, c1n = r - gamma;
-        const bool big = r - l + 1u > kFineMax;
-        const bool f0 = big && c0n <= kFineMax, f1 = big && c1n <= kFineMax;
-        if (f0 || f1) {
-            // collected in LDS and written out together: one update of the counter in memory per workgroup
-            const uint32_t cnt = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
-            const uint32_t at = atomicAdd(&s_nfine, cnt);
-            const uint32_t nlocal = at < kLevelFine ? min(cnt, kLevelFine - at) : 0u; // of this node's records, in LDS
-            const uint32_t gat = nlocal < cnt ? atomicAdd(fine_count, cnt - nlocal) : 0u;
-            uint32_t j = 0;
-            if (f0) {
-                const float4 q0 = make_float4(b0[0], b0[1], b0[2], __uint_as_float(l));
-                const float4 q1 = make_float4(b0[3], b0[4], b0[5], __uint_as_float(c0n));
-                if (j < nlocal)
-                    s_fine[2 * (at + j)] = q0, s_fine[2 * (at + j) + 1] = q1;
-                else if (gat + j - nlocal < fine_cap)
-                    ((float4*)fine)[2 * (size_t)(gat + j - nlocal)] = q0, ((float4*)fine)[2 * (size_t)(gat + j - nlocal) + 1] = q1;
-                j++;
-            }
-            if (f1) {
-                const float4 q0 = make_float4(b1[0], b1[1], b1[2], __uint_as_float(gamma + 1u));
-                const float4 q1 = make_float4(b1[3], b1[4], b1[5], __uint_as_float(c1n));
-                if (j < nlocal)
-                    s_fine[2 * (at + j)] = q0, s_fine[2 * (at + j) + 1] = q1;
-                else if (gat + j - nlocal < fine_cap)
-                    ((float4*)fine)[2 * (size_t)(gat + j - nlocal)] = q0, ((float4*)fine)[2 * (size_t)(gat + j - nlocal) + 1] = q1;
+    {
+        const uint32_t g = tid;
+        if (g + 1u < M && s_flag[g] == kMerged) {
+            made = 1u;
+            const float4 p0 = s_slot[2u * g][0], p1 = s_slot[2u * g][1], q0 = s_slot[2u * g + 1u][0], q1 = s_slot[2u * g + 1u][1];
+            const float b0[6] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z}, b1[6] = {q0.x, q0.y, q0.z, q1.x, q1.y, q1.z};
+            const uint32_t me = s_nme[g], l = __float_as_uint(p0.w), r = __float_as_uint(q1.w);
+            const uint32_t gamma = __float_as_uint(p1.w); // last leaf of the left child
+            const bool leaf0 = l == gamma, leaf1 = gamma + 1u == r;
+            const uint32_t c0 = gamma | (leaf0 ? 0x80000000u : 0u), c1 = (gamma + 1u) | (leaf1 ? 0x80000000u : 0u);
+            if (me + 1u < n) { // (always, with whole input: a name is a leaf with a neighbour on the named side)
+                float4* nd = (float4*)nodes + 4 * (size_t)me;
+                nd[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+                nd[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+                nd[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+                nd[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(l), __uint_as_float(r));
+                if (l == 0u && r == n - 1u) { // the root: its box and height, for the build's summary
+                    float4* ub = (float4*)union_box;
+                    const uint32_t h0 = s_sh[2u * g], h1 = s_sh[2u * g + 1u];
+                    ub[0] = make_float4(fminf(b0[0], b1[0]), fminf(b0[1], b1[1]), fminf(b0[2], b1[2]), fmaxf(b0[3], b1[3]));
+                    ub[1] = make_float4(fmaxf(b0[4], b1[4]), fmaxf(b0[5], b1[5]), __uint_as_float(1u + (h0 > h1 ? h0 : h1)), 0.0f);
+                    *root_done = 1u;
+                }
+                const uint32_t c0n = gamma - l + 1u, c1n = r - gamma;
+                const bool big = r - l + 1u > kFineMax;
+                const bool f0 = big && c0n <= kFineMax, f1 = big && c1n <= kFineMax;
+                if (f0 || f1) {
+                    // collected in LDS and written out together: one update of the counter in memory per workgroup
+                    const uint32_t cnt = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
+                    const uint32_t at = atomicAdd(&s_nfine, cnt);
+                    const uint32_t nlocal = at < kLevelFine ? min(cnt, kLevelFine - at) : 0u; // of this node's records, in LDS
+                    const uint32_t gat = nlocal < cnt ? atomicAdd(fine_count, cnt - nlocal) : 0u;
+                    uint32_t j = 0;
+                    if (f0) {
+                        const float4 r0 = make_float4(b0[0], b0[1], b0[2], __uint_as_float(l));
+                        const float4 r1 = make_float4(b0[3], b0[4], b0[5], __uint_as_float(c0n));
+                        if (j < nlocal)
+                            s_fine[2 * (at + j)] = r0, s_fine[2 * (at + j) + 1] = r1;
+                        else if (gat + j - nlocal < fine_cap)
+                            ((float4*)fine)[2 * (size_t)(gat + j - nlocal)] = r0, ((float4*)fine)[2 * (size_t)(gat + j - nlocal) + 1] = r1;
+                        j++;
+                    }
+                    if (f1) {
+                        const float4 r0 = make_float4(b1[0], b1[1], b1[2], __uint_as_float(gamma + 1u));
+                        const float4 r1 = make_float4(b1[3], b1[4], b1[5], __uint_as_float(c1n));
+                        if (j < nlocal)
+                            s_fine[2 * (at + j)] = r0, s_fine[2 * (at + j) + 1] = r1;
+                        else if (gat + j - nlocal < fine_cap)
+                            ((float4*)fine)[2 * (size_t)(gat + j - nlocal)] = r0, ((float4*)fine)[2 * (size_t)(gat + j - nlocal) + 1] = r1;
+                    }
+                }
             }
         }
     }
     for (int off = 32; off > 0; off >>= 1) made += __shfl_down(made, off);
     if (lane == 0 && made) atomicAdd(&s_made, made);
-    // the tops this workgroup hands up, in leaf order (the carried item lies in the subtree it was carried into)
-    uint32_t before = 0; // tops of the rounds before this one
-    for (uint32_t k0 = 0; k0 < M; k0 += kLevelThreads) { // block-uniform
-        const uint32_t k = k0 + tid;
-        bool top = false;
-        uint32_t e = 0;
-        if (k < M) {
-            e = s_exit[k];
-            const int gp = (int)(e >> 16) - 1;
-            top = e != 0xFFFFFFFFu && (gp < 0 || gp >= (int)M - 1 || s_flag[gp] != kMerged);
-        }
+    // the tops this workgroup hands up, in leaf order: the lane that carried a subtree to where it stopped holds it, and
+    // the lanes' own items lie in their subtrees, so the order of the lanes is the order of the subtrees
+    uint32_t before = 0;
+    {
+        const bool top = k < M && exit_gp != -2 && (exit_gp < 0 || exit_gp >= (int)M - 1 || s_flag[exit_gp] != kMerged);
         const uint64_t m = __ballot(top);
-        __syncthreads(); // s_wcount of the round before has been read
         if (lane == 0) s_wcount[wave] = (uint32_t)__popcll(m);
         __syncthreads();
-        uint32_t at = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), round = 0;
+        uint32_t at = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         for (uint32_t w = 0; w < kLevelThreads / 64u; w++) {
             if (w < wave) at += s_wcount[w];
-            round += s_wcount[w];
+            before += s_wcount[w];
         }
         if (top && at < top_cap) {
-            const uint32_t ref = e & 0xFFFFu, i = ref & 0x7FFFu;
-            const bool nd = (ref & 0x8000u) != 0u;
-            const uint32_t il = nd ? s_nit[i] & 0xFFFFu : i, ir = nd ? s_nit[i] >> 16 : i;
             float4* o = tops_out + 3 * ((size_t)blockIdx.x * kTopCap + at);
-            o[0] = make_float4(nd ? s_nbox[0][i] : s_ibox[0][i], nd ? s_nbox[1][i] : s_ibox[1][i], nd ? s_nbox[2][i] : s_ibox[2][i],
-                               __uint_as_float(nd ? s_nl[i] : s_il[i]));
-            o[1] = make_float4(nd ? s_nbox[3][i] : s_ibox[3][i], nd ? s_nbox[4][i] : s_ibox[4][i], nd ? s_nbox[5][i] : s_ibox[5][i],
-                               __uint_as_float(nd ? s_nr[i] : s_ir[i]));
-            o[2] = make_float4(__uint_as_float((uint32_t)(s_delta[il] + 1) | ((uint32_t)(s_delta[ir + 1u] + 1) << 8) |
-                                               ((nd ? s_nh[i] : s_ih[i]) << 16)), 0.0f, 0.0f, 0.0f);
+            o[0] = make_float4(lo4.x, lo4.y, lo4.z, lo4.w);
+            o[1] = make_float4(hi4.x, hi4.y, hi4.z, hi4.w);
+            o[2] = make_float4(__uint_as_float((uint32_t)(dl + 1) | ((uint32_t)(dr + 1) << 8) | (h << 16)), 0.0f, 0.0f, 0.0f);
         }
-        before += round;
     }
     __syncthreads(); // s_made and s_nfine are complete
     // (s_nfine also counts the records that did not fit and went to memory at once: the first kLevelFine are in LDS)
@@ -1202,11 +1218,13 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
                                                           const uint32_t* __restrict__ unsorted,
                                                           const uint32_t* __restrict__ overflow,
                                                           const float* __restrict__ bbox,
-                                                          const float* __restrict__ union_box,
+                                                          const float* __restrict__ union_box, uint32_t n,
                                                           uint32_t* __restrict__ summary) {
     __shared__ uint32_t frontier[2][kCutCap]; // (parent << 1) | side
     __shared__ uint32_t tot[2][kCutThreads / 64];
+    __shared__ uint32_t s_bad; // a record names a node that does not exist: the tree is not what it should be
     const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_bad = 0u;
     // block-uniform (unsorted: the sort gave up; overflow: the bottom-up build gave up: the tree is not to be read)
     if (*root_done == 0u || *unsorted != 0u || *overflow != 0u) {
         if (tid == 0) summary[0] = kCutUnfinished;
@@ -1239,6 +1257,7 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
                 const uint32_t first = side ? gamma + 1u : lo;
                 count[j] = side ? hi - gamma : gamma - lo + 1u;
                 small[j] = (c & 0x80000000u) || count[j] <= kRangeMax;
+                if (!small[j] && c + 1u >= n) small[j] = true, s_bad = 1u; // (never followed)
                 ref[j] = small[j] ? first : c;
                 childref[j] = c;
 #pragma unroll
@@ -1269,7 +1288,7 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
         cur ^= 1;
         __syncthreads();
     }
-    if (tid == 0) summary[0] = nout;
+    if (tid == 0) summary[0] = s_bad ? kCutUnfinished : nout;
     __threadfence_block();
     __syncthreads(); // the records are read back below by other lanes of this workgroup
     // boxes of kCutGroup consecutive records (breadth-first order keeps neighbours together): 8 floats per group
@@ -1423,7 +1442,7 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     uint32_t* vin = (steps & 1) ? vals_alt : sc.order;
     uint64_t* kout = (steps & 1) ? sc.morton : keys_alt;
     uint32_t* vout = (steps & 1) ? sc.order : vals_alt;
-    static_assert(kSortTile == 2048 && kSortThreads == 256, "k_morton counts the digits of one sort tile per workgroup");
+    static_assert(kSortThreads == 256, "k_morton counts the digits of one sort tile per workgroup");
     hipLaunchKernelGGL(k_morton, dim3(ntiles), blk, 0, s, T0, mesh, n, d_bbox, kin, vin, sort_shift, ntiles, counts);
     for (int pass = sort_shift / 8; pass < 8; pass++) {
         const int shift = 8 * pass;
@@ -1493,7 +1512,7 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     hipLaunchKernelGGL(k_build_cut, dim3(1), dim3(kCutThreads), 0, s, (const float*)sc.nodes, sc.cut, sc.cut_groups,
                        (const uint32_t*)(words + kWRootDone), (const uint32_t*)too_long, (const uint32_t*)(words + kWOverflow),
                        (const float*)d_bbox,
-                       (const float*)union_box, words + kWSummary);
+                       (const float*)union_box, n, words + kWSummary);
     HIP_RET(hipGetLastError());
     uint32_t host_words[kWords] = {0};
     const uint32_t* summary = host_words + kWSummary;
