@@ -1180,31 +1180,20 @@ __global__ __launch_bounds__(kClimbThreads) void k_refit_climb(const float4* __r
 //    level by level, until every open subtree has at most kRangeMax leaves or kCutCap records are in
 //    use.  A record is 8 floats: (lo.xyz, ref) (hi.xyz, count).  count <= kRangeMax: ref is the first
 //    sorted leaf of a range taken whole; otherwise ref is an internal node that still has to be
-//    descended.  One workgroup: the frontier (at most kCutCap entries) lives in LDS, two entries per
-//    lane, and order-preserving block scans place the records and the next frontier, so the result
-//    does not depend on scheduling.
+//    descended.  One workgroup, a lane per open node (its two sides are two pending records, one after the
+//    other), the open nodes' own records in LDS; an order-preserving block scan places the records and the
+//    next level's nodes, so the result does not depend on scheduling.
+//    The time of this kernel is the number of levels times what a level waits for, so a level waits for as little
+//    as it can: a lane asks for the records of its node's children as soon as it knows them, before the scan and
+//    its barriers (which wait for LDS only), and whoever is opened puts the record that has arrived into the
+//    next level's place.  Nothing is stored to memory on the way (loads and stores are counted together, in order:
+//    a level's wait for its loads would wait for the stores of the level before, some 2 us each); the cut's
+//    records collect in LDS and leave together at the end.
 // ------------------------------------------------------------------------------------------
 constexpr int kCutThreads = kCutCap / 2;
 
-// Exclusive ranks, in entry order, of two flags per lane (entry tid and entry tid + kCutThreads); returns the total.
-__device__ __forceinline__ uint32_t block_ranks(bool f0, bool f1, uint32_t (*tot)[kCutThreads / 64], uint32_t& r0,
-                                                uint32_t& r1) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
-    const uint64_t below = (1ull << lane) - 1ull;
-    __syncthreads(); // the totals of the previous scan have been read
-    if (lane == 0) tot[0][wave] = (uint32_t)__popcll(m0), tot[1][wave] = (uint32_t)__popcll(m1);
-    __syncthreads();
-    uint32_t before0 = 0, before1 = 0, all0 = 0, all1 = 0;
-    for (uint32_t w = 0; w < kCutThreads / 64; w++) {
-        const uint32_t a = tot[0][w], b = tot[1][w];
-        if (w < wave) before0 += a, before1 += b;
-        all0 += a, all1 += b;
-    }
-    r0 = before0 + (uint32_t)__popcll(m0 & below);
-    r1 = all0 + before1 + (uint32_t)__popcll(m1 & below);
-    return all0 + all1;
-}
+// A barrier that waits for the wave's LDS operations only: loads from memory stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The host queues this kernel behind the refit without knowing whether it reached the root: while `root_done` is
 // zero the node records are not complete and nothing is read.  summary: [0] number of cut records (kCutUnfinished: refit not finished), [1..6] scene bounds,
@@ -1220,11 +1209,12 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
                                                           const float* __restrict__ bbox,
                                                           const float* __restrict__ union_box, uint32_t n,
                                                           uint32_t* __restrict__ summary) {
-    __shared__ uint32_t frontier[2][kCutCap]; // (parent << 1) | side
-    __shared__ uint32_t tot[2][kCutThreads / 64];
+    __shared__ float4 s_rec[4][kCutThreads]; // the records of the open nodes, in breadth-first order, a quarter per row
+    __shared__ float4 s_cut[2][kCutCap];     // the cut's records (a half per row): written to memory together at the end
+    __shared__ uint32_t s_tot[kCutThreads / 64];
     __shared__ uint32_t s_bad; // a record names a node that does not exist: the tree is not what it should be
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_bad = 0u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const float4* const nodes4 = (const float4*)nodes;
     // block-uniform (unsorted: the sort gave up; overflow: the bottom-up build gave up: the tree is not to be read)
     if (*root_done == 0u || *unsorted != 0u || *overflow != 0u) {
         if (tid == 0) summary[0] = kCutUnfinished;
@@ -1232,75 +1222,87 @@ __global__ __launch_bounds__(kCutThreads) void k_build_cut(const float* __restri
     }
     if (tid < 6) summary[1 + tid] = __float_as_uint(bbox[tid]);
     if (tid == 6) summary[7] = __float_as_uint(union_box[6]);
-    if (tid == 0) frontier[0][0] = 0u, frontier[0][1] = 1u; // the root's two sides
-    uint32_t nf = 2, nout = 0; // block-uniform
-    int cur = 0;
+    if (tid == 0) s_bad = 0u;
+    if (tid < 4) s_rec[tid][0] = nodes4[tid]; // the root
+    uint32_t nn = 1, nout = 0; // open nodes, records written (block-uniform)
     __syncthreads();
-    while (nf != 0) {
+    while (nn != 0) {
         // opening a subtree replaces one pending record by two: at most `budget` more may be opened
-        const uint32_t budget = kCutCap - (nout + nf);
-        bool have[2], small[2];
-        uint32_t ref[2], count[2], childref[2];
-        float box[2][6];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint32_t e = tid + j * kCutThreads;
-            have[j] = e < nf;
-            small[j] = true, ref[j] = 0, count[j] = 0, childref[j] = 0;
-            if (have[j]) {
-                const uint32_t ent = frontier[cur][e];
-                const uint32_t parent = ent >> 1, side = ent & 1u;
-                const float* nd = nodes + 16 * (size_t)parent;
-                const uint32_t c = __float_as_uint(nd[12 + side]);
-                const uint32_t gamma = __float_as_uint(nd[12]) & 0x7FFFFFFFu;
-                const uint32_t lo = __float_as_uint(nd[14]), hi = __float_as_uint(nd[15]);
-                const uint32_t first = side ? gamma + 1u : lo;
-                count[j] = side ? hi - gamma : gamma - lo + 1u;
-                small[j] = (c & 0x80000000u) || count[j] <= kRangeMax;
-                if (!small[j] && c + 1u >= n) small[j] = true, s_bad = 1u; // (never followed)
-                ref[j] = small[j] ? first : c;
-                childref[j] = c;
-#pragma unroll
-                for (int a = 0; a < 6; a++) box[j][a] = nd[6 * side + a];
+        const uint32_t budget = kCutCap - (nout + 2u * nn);
+        const bool have = tid < nn;
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        uint32_t c0 = 0, c1 = 0, first0 = 0, first1 = 0, cnt0 = 0, cnt1 = 0;
+        bool big0 = false, big1 = false; // the sides that are opened if the budget allows
+        float4 a0 = q0, a1 = q0, a2 = q0, a3 = q0, b0 = q0, b1 = q0, b2 = q0, b3 = q0; // the children's records, on their way
+        if (have) {
+            q0 = s_rec[0][tid], q1 = s_rec[1][tid], q2 = s_rec[2][tid];
+            const float4 q3 = s_rec[3][tid];
+            c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            const uint32_t lo = __float_as_uint(q3.z), hi = __float_as_uint(q3.w), gamma = c0 & 0x7FFFFFFFu;
+            first0 = lo, cnt0 = gamma - lo + 1u, first1 = gamma + 1u, cnt1 = hi - gamma;
+            big0 = !(c0 & 0x80000000u) && cnt0 > kRangeMax, big1 = !(c1 & 0x80000000u) && cnt1 > kRangeMax;
+            if (big0 && c0 + 1u >= n) big0 = false, s_bad = 1u; // (never followed)
+            if (big1 && c1 + 1u >= n) big1 = false, s_bad = 1u;
+            // (with no budget left -- the last level -- nothing will be opened: no loads)
+            if (big0 && budget) a0 = nodes4[4 * (size_t)c0], a1 = nodes4[4 * (size_t)c0 + 1], a2 = nodes4[4 * (size_t)c0 + 2], a3 = nodes4[4 * (size_t)c0 + 3];
+            if (big1 && budget) b0 = nodes4[4 * (size_t)c1], b1 = nodes4[4 * (size_t)c1 + 1], b2 = nodes4[4 * (size_t)c1 + 2], b3 = nodes4[4 * (size_t)c1 + 3];
+        }
+        // the big sides before each side, in record order (node p's sides are records 2 p and 2 p + 1)
+        const uint64_t m0 = __ballot(big0), m1 = __ballot(big1), below = (1ull << lane) - 1ull;
+        if (lane == 0) s_tot[wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
+        lds_barrier(); // (every lane has read its node's record)
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < kCutThreads / 64; w++) {
+            const uint32_t c = s_tot[w];
+            if (w < wave) before += c;
+            all += c;
+        }
+        const uint32_t o0 = before + (uint32_t)(__popcll(m0 & below) + __popcll(m1 & below)), o1 = o0 + (big0 ? 1u : 0u);
+        const bool open0 = big0 && o0 < budget, open1 = big1 && o1 < budget;
+        const uint32_t opened = min(all, budget);
+        // (The wait is written out: the compiler waits for a load where its value is used, which is under a condition
+        // here, and then has to wait again, wherever the same registers are written next, for the loads nobody used.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (open0) s_rec[0][o0] = a0, s_rec[1][o0] = a1, s_rec[2][o0] = a2, s_rec[3][o0] = a3;
+        if (open1) s_rec[0][o1] = b0, s_rec[1][o1] = b1, s_rec[2][o1] = b2, s_rec[3][o1] = b3;
+        if (have) {
+            // a record that is not opened is written out: its place is its number less the opened ones before it
+            if (!open0) {
+                const uint32_t at = nout + 2u * tid - min(o0, budget);
+                s_cut[0][at] = make_float4(q0.x, q0.y, q0.z, __uint_as_float(big0 ? c0 : first0));
+                s_cut[1][at] = make_float4(q0.w, q1.x, q1.y, __uint_as_float(cnt0));
+            }
+            if (!open1) {
+                const uint32_t at = nout + 2u * tid + 1u - min(o1, budget);
+                s_cut[0][at] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(big1 ? c1 : first1));
+                s_cut[1][at] = make_float4(q2.y, q2.z, q2.w, __uint_as_float(cnt1));
             }
         }
-        uint32_t o0, o1;
-        block_ranks(have[0] && !small[0], have[1] && !small[1], tot, o0, o1);
-        const bool open0 = have[0] && !small[0] && o0 < budget, open1 = have[1] && !small[1] && o1 < budget;
-        uint32_t e0, e1;
-        const uint32_t emitted = block_ranks(have[0] && !open0, have[1] && !open1, tot, e0, e1);
-        const uint32_t opened = nf - emitted;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const bool open = j ? open1 : open0;
-            if (have[j] && open) {
-                const uint32_t at = 2u * (j ? o1 : o0);
-                frontier[cur ^ 1][at] = 2u * childref[j];
-                frontier[cur ^ 1][at + 1u] = 2u * childref[j] + 1u;
-            } else if (have[j]) {
-                float* r = cut + 8 * (size_t)(nout + (j ? e1 : e0));
-                r[0] = box[j][0], r[1] = box[j][1], r[2] = box[j][2], r[3] = __uint_as_float(ref[j]);
-                r[4] = box[j][3], r[5] = box[j][4], r[6] = box[j][5], r[7] = __uint_as_float(count[j]);
-            }
-        }
-        nout += emitted;
-        nf = 2u * opened;
-        cur ^= 1;
-        __syncthreads();
+        nout += 2u * nn - opened;
+        nn = opened;
+        lds_barrier(); // the next level's records are in place, s_tot has been read
     }
+    __syncthreads();
     if (tid == 0) summary[0] = s_bad ? kCutUnfinished : nout;
-    __threadfence_block();
-    __syncthreads(); // the records are read back below by other lanes of this workgroup
-    // boxes of kCutGroup consecutive records (breadth-first order keeps neighbours together): 8 floats per group
-    for (uint32_t g = tid; g * kCutGroup < nout; g += kCutThreads) {
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t i = g * kCutGroup; i < nout && i < (g + 1) * kCutGroup; i++)
-            for (int a = 0; a < 3; a++) {
-                lo[a] = fminf(lo[a], cut[8 * (size_t)i + a]);
-                hi[a] = fmaxf(hi[a], cut[8 * (size_t)i + 4 + a]);
-            }
-        float* r = groups + 8 * (size_t)g;
-        r[0] = lo[0], r[1] = lo[1], r[2] = lo[2], r[3] = 0.0f, r[4] = hi[0], r[5] = hi[1], r[6] = hi[2], r[7] = 0.0f;
+    // The records go to memory, and with them the boxes of kCutGroup consecutive records (breadth-first order keeps
+    // neighbours together), 8 floats per group: a lane per record, then the group's lanes put their boxes together.
+    static_assert(kCutGroup == 16, "sixteen consecutive lanes make a group");
+    for (uint32_t i0 = 0; i0 < nout; i0 += kCutThreads) { // block-uniform
+        const uint32_t i = i0 + tid;
+        float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+        if (i < nout) {
+            lo = s_cut[0][i], hi = s_cut[1][i];
+            ((float4*)cut)[2 * (size_t)i] = lo, ((float4*)cut)[2 * (size_t)i + 1] = hi;
+        }
+#pragma unroll
+        for (int o = 1; o < (int)kCutGroup; o <<= 1) {
+            lo.x = fminf(lo.x, __shfl_xor(lo.x, o)), lo.y = fminf(lo.y, __shfl_xor(lo.y, o)), lo.z = fminf(lo.z, __shfl_xor(lo.z, o));
+            hi.x = fmaxf(hi.x, __shfl_xor(hi.x, o)), hi.y = fmaxf(hi.y, __shfl_xor(hi.y, o)), hi.z = fmaxf(hi.z, __shfl_xor(hi.z, o));
+        }
+        if (i < nout && (tid & (kCutGroup - 1u)) == 0u) {
+            float4* r = (float4*)groups + 2 * (size_t)(i / kCutGroup);
+            r[0] = make_float4(lo.x, lo.y, lo.z, 0.0f), r[1] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+        }
     }
 }
 
