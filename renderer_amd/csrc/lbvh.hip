@@ -858,7 +858,7 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
     __shared__ uint32_t s_nme[kLevelItems];   // per split: the name of the node made there
     // per split: 0, or what the first child to arrive left (its far item + 1 | the prefix beyond that end + 1 << 10), or kMerged
     __shared__ uint32_t s_flag[kLevelItems];
-    __shared__ uint32_t s_off[kLevelUnits + 1], s_wcount[kLevelThreads / 64], s_made, s_nfine, s_fbase;
+    __shared__ uint32_t s_wcount[kLevelThreads / 64], s_made, s_nfine, s_fbase;
     __shared__ float4 s_fine[2 * kLevelFine]; // the fine cut's records made here, written out together at the end
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t u0 = blockIdx.x * kLevelUnits, nu = min(kLevelUnits, nunits - u0);
@@ -867,26 +867,20 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
     // then done again the other way; this launch and those after it do nothing.  (One lane reads the flag for all:
     // another workgroup of this very launch may raise it meanwhile, and the lanes must agree.)
     __shared__ uint32_t s_stop;
-    if (tid == 0) s_stop = *overflow;
-    __syncthreads();
-    if (s_stop != 0u) return;
     static_assert(kLevelUnits <= 64u && kLevelItems <= kLevelThreads && kLevelItems <= 1023u,
-                  "one wave adds up the units' counts; a lane per item; an item's index + 1 fits ten bits of the flag");
-    if (tid < 64u) {
-        const uint32_t c = tid < nu ? min(counts_in[u0 + tid], top_cap) : 0u;
-        uint32_t incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += v;
-        }
-        if (tid < nu) s_off[tid] = incl - c;
-        if (tid == nu - 1u) s_off[nu] = incl;
-        if (tid == 0) s_made = 0u, s_nfine = 0u;
-    }
+                  "a wave adds up the units' counts; a lane per item; an item's index + 1 fits ten bits of the flag");
+    // (every wave adds up the units' counts for itself, asked for together with the flag: one wait for memory, no LDS)
+    uint32_t incl = lane < nu ? min(counts_in[u0 + lane], top_cap) : 0u;
+    if (tid == 0) s_stop = *overflow, s_made = 0u, s_nfine = 0u;
     if (tid < kLevelItems) s_flag[tid] = 0u;
     __syncthreads();
-    const uint32_t M = s_off[nu];
+    if (s_stop != 0u) return;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += v;
+    }
+    const uint32_t M = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); // items in all (lanes past the units add nothing)
     if (M > kLevelItems) { // block-uniform: more tops than fit (a very unbalanced tree)
         if (tid == 0) *overflow = 1u, counts_out[blockIdx.x] = 0u;
         return;
@@ -898,9 +892,15 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
     int dl = -1, dr = -1;                        // the prefixes beyond its two ends
     int exit_gp = -2; // the split the subtree waits at; outside [0, M - 2]: the sibling is another workgroup's; -2: no subtree, or the root
     if (k < M) {
-        uint32_t u = 0;
-        while (s_off[u + 1u] <= k) u++;
-        const float4* it = tops_in + 3 * ((size_t)(u0 + u) * kTopCap + (k - s_off[u]));
+        // item k is item k - off of unit u: u units end at or before k, the last of them at off
+        uint32_t u = 0, off = 0;
+#pragma unroll
+        for (int j = 0; j < (int)kLevelUnits; j++) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)incl, j);
+            const bool past = e <= k;
+            u += past ? 1u : 0u, off = past ? e : off;
+        }
+        const float4* it = tops_in + 3 * ((size_t)(u0 + u) * kTopCap + (k - off));
         const float4 a = it[0], b = it[1], c = it[2];
         lo4 = (v4f){a.x, a.y, a.z, a.w}, hi4 = (v4f){b.x, b.y, b.z, b.w};
         const uint32_t w = __float_as_uint(c.x);
