@@ -27,7 +27,7 @@ def main():
         "pmc_cache.txt": "l2_valu_counters.txt", "build_timeline.txt": "lbvh_build_timeline.txt", "pmc_ao.txt": "ao_instruction_mix.txt",
         "bench_ao64_closeup.json": "bench_bunny_1080p_ao64_closeup.json", "bench_single_draw.json": "bench_bunny_1080p_single_draw.json",
         "pmc_4k.txt": "4k_16spp_counters.txt", "pmc_read_hit.txt": "l2_read_hit_rate.txt", "bench_x13924.json": "bench_bunny_x13924_1080p.json",
-        "config4_118.txt": "config4_69m.txt", "memset_probe.txt": "memset_probe.txt", "fill_probe.txt": "fill_probe.txt", "pmc_x1024.txt": "x1024_counters.txt", "build_probe.txt": "build_probe.txt",
+        "config4_118.txt": "config4_69m.txt", "memset_probe.txt": "memset_probe.txt", "fill_probe.txt": "fill_probe.txt", "pmc_x1024.txt": "x1024_counters.txt", "build_probe.txt": "build_probe.txt", "pmc_build.txt": "build_counters.txt", "build_timeline_118.txt": "lbvh_build_timeline_69m.txt",
     }
     for s, d in names.items():
         p = os.path.join(src, s)

@@ -28,12 +28,13 @@ timeout -k 10 120 python3 tools/phase_timing.py --flags 67 > "$O/phase_timing_bl
 bash tools/pmc_phases.sh > /dev/null 2>&1 && cp gpurun_out/pmc_phases.txt "$O/pmc_phases.txt"
 timeout -k 10 300 python3 tools/config4.py > "$O/config4.txt" 2>&1
 (cd /tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d "$O/build_trace" -- python3 $R/tools/config4.py --builds 8 > /dev/null 2>&1)
-python3 tools/build_timeline.py "$O"/build_trace/*/*_kernel_trace.csv > "$O/build_timeline.txt" 2>&1
+python3 tools/build_timeline.py "$O"/build_trace/*/*_kernel_trace.csv -v > "$O/build_timeline.txt" 2>&1
 bash tools/pmc_cache.sh > /dev/null 2>&1 && cp gpurun_out/pmc_cache.txt "$O/pmc_cache.txt"
 bash tools/pmc_ao.sh > /dev/null 2>&1 && cp gpurun_out/pmc_ao.txt "$O/pmc_ao.txt"
 bash tools/pmc_4k.sh > "$O/pmc_4k.txt" 2>&1
 bash tools/pmc_x1024.sh > "$O/pmc_x1024.txt" 2>&1
 timeout -k 10 200 python3 tools/build_probe.py > "$O/build_probe.txt" 2>&1
+KERNELS="k_build_chunks k_build_level k_build_cut k_sort_scatter k_sort_hist k_sort_runs k_morton" bash tools/pmc_build.sh > "$O/pmc_build.txt" 2>&1
 # the 5 M-triangle frame and its scene builds: kernel statistics and HBM bytes (FETCH_SIZE, WRITE_SIZE: a pass each)
 BX="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 2 --warmup 1 --warmup-ms 0 --frames-per-step 8 --workload bunny_x1024_1080p"
 (cd /tmp && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_x1024" -- $BX > /dev/null 2>&1)
@@ -42,6 +43,8 @@ BX="python3 $R/bench.py --no-cpu-baseline --no-extra-passes --steps 2 --warmup 1
 bash tools/pmc_read_hit.sh > /dev/null 2>&1 && cp gpurun_out/pmc_read_hit.txt "$O/pmc_read_hit.txt"
 timeout -k 10 250 python3 bench.py --workload bunny_x13924_1080p --no-cpu-baseline --steps 3 --warmup 1 --frames-per-step 8 > "$O/bench_x13924.json"
 timeout -k 10 250 python3 tools/config4.py --side 118 --builds 5 > "$O/config4_118.txt" 2>&1
+(cd /tmp && timeout -s KILL 250 rocprofv3 --kernel-trace --output-format csv -d "$O/build_trace_118" -- python3 $R/tools/config4.py --side 118 --builds 3 > /dev/null 2>&1)
+python3 tools/build_timeline.py "$O"/build_trace_118/*/*_kernel_trace.csv -v > "$O/build_timeline_118.txt" 2>&1
 timeout -k 10 120 python3 tools/memset_probe.py > "$O/memset_probe.txt" 2>&1
 INVERT_HIP_LIB=$R/renderer_amd/libinvert_hip_timing.so timeout -k 10 200 python3 tools/fill_probe.py timing-build > "$O/fill_probe.txt" 2>&1
 echo done
