@@ -288,6 +288,9 @@ def main():
                          "from close by) that follow the timed region and show where sharding pays")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on one GPU (ranks share cuda:0, gather through host memory)")
+    ap.add_argument("--extras-watchdog-seconds", type=float, default=240.0,
+                    help="N > 1: the passes over the heavier workloads that follow the timed region are given up after this "
+                         "long; the line is then printed without them, with a note (0: off)")
     ap.add_argument("--watchdog-seconds", type=int, default=900,
                     help="a rank still running after this long writes every thread's Python stack to standard error and "
                          "exits with a failure, so that a collective that never completes ends the run with a message "
@@ -628,113 +631,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    # Several ranks: the headline frame is bound by rank 0's own stores (every pixel of every frame is written into
-    # rank 0's HBM whatever N is), so sharding cannot pay there; these short passes (not part of `value`) time the
-    # timed workload and the two heavier ones the same way, as a stream of frames in groups of `xf` per submission
-    # and per gather on two buffer sets: the sharded draws alone, the draws plus the composite, and the whole frames
-    # on one GPU (rank 0 alone on two frame slots, the others idle); per frame, max over ranks.
-    extra, scaling_workloads = {}, {}
-    if world > 1 and sparse and not args.no_extra_workloads:
-        rehearsal = args.backend != "nccl"  # ranks sharing one GPU: enough frames to see that it works
-
-        def timed(body, n, frames_each):
-            torch.cuda.synchronize()
-            dist.barrier()
-            t_0 = time.perf_counter()
-            for i in range(n):
-                body(i)
-            ctx.frames_join()
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt[0]) / (n * frames_each) * 1e3
-
-        trace_on = bool(os.environ.get("INV_BENCH_TRACE"))
-
-        def trace(*what):  # where a rank is, for a run that has to be looked into
-            if trace_on:
-                print("bench.py trace: rank %d" % rank, *what, file=sys.stderr, flush=True)
-
-        names = [args.workload] + [n_ for n_ in ("bunny_4k_16spp", "bunny_1080p_ao64_closeup") if n_ != args.workload]
-        for name in names:
-            trace(name, "begin")
-            xw = WORKLOADS[name]
-            if xw.get("instances_side", 1) != side or xw.get("turntable"):
-                continue  # another scene than the one built
-            ew, eh = xw["width"], xw["height"]
-            ecam = R.camera_reference(ew, eh)
-            if side > 1:
-                ecam = common.grid_camera(ecam, side)
-            if "view_translation" in xw:
-                ecam.view[12], ecam.view[13], ecam.view[14] = xw["view_translation"]
-            kw = dict(spp=xw["spp"], flags=xw["flags"], ao_rays=xw.get("ao_rays", 0))
-            heavy = bool(kw["ao_rays"]) or ew * eh * kw["spp"] > 1 << 26
-            xf = (2 if rehearsal else 4) if heavy else (4 if rehearsal else 8)  # frames per group
-            n_x = 2 if rehearsal else (6 if heavy else 24)                      # groups timed
-            # the whole frames on one GPU: rank 0 alone, groups of xf frames on two frame slots in turn
-            eprm = R.make_params(ew, eh, **kw)
-            one_ms, one = None, None
-            if rank == 0:
-                one = torch.empty(2, xf, 3, eh * ew, dtype=torch.int32, device="cuda")
-                one_batches = [scene.make_batch([ecam] * xf, [eprm] * xf,
-                                                [tuple(one[j, u, p_].data_ptr() for p_ in range(3)) for u in range(xf)])
-                               for j in range(2)]
-
-            # (Ranks that share one GPU, occlusion rays: on one slot.  With a second process on the device, rank 0's
-            # occlusion frames on two slots at once have now and then never completed -- one run in seven, only in
-            # this pass, never with one process per GPU or with one process alone, 40 fresh processes and 900 frames
-            # in tools/ao_two_slots_probe.py -- and a rehearsal's times mean nothing anyway.)
-            one_slot = rehearsal and bool(kw["ao_rays"])
-
-            def alone(i):
-                if rank == 0:
-                    scene.render_batch(one_batches[i % 2], 0 if one_slot else i % 2)
-
-            alone(0)
-            alone(1)
-            trace(name, "one GPU: warmed")
-            one_ms = timed(alone, n_x, xf)
-            trace(name, "one GPU: timed")
-            for share, share_flag in [("equal", 0)] + ([("rank0_idle", R.ROOT_IDLE)] if world >= 3 else []):
-                ecb = RD.SparseCompositeBatch(scene, ecam, ew, eh, rank, world, frames=xf, sets=2, tile=32, comm=comm,
-                                              **dict(kw, flags=kw["flags"] | share_flag))
-
-                def draws(i):
-                    ecb.render(i % 2, xf)
-
-                def both(i):
-                    ecb.render(i % 2, xf)
-                    composite_group(ecb, i % 2, xf)
-
-                trace(name, share, "composite made")
-                for i in range(2):
-                    both(i)
-                render_ms = timed(draws, n_x, xf)
-                trace(name, share, "draws timed")
-                both_ms = timed(both, n_x, xf)
-                trace(name, share, "draws + composite timed")
-                both(0)
-                ctx.frames_join()
-                torch.cuda.synchronize()
-                ok = all(bool(torch.equal(one[0, 0], ecb.frames[0][u])) for u in range(xf)) if rank == 0 else True
-                res = {"render_only_ms": render_ms, "render_plus_gather_ms": both_ms, "one_gpu_ms": one_ms,
-                       "composite_equals_one_gpu_frame": ok, "frames_timed": n_x * xf, "frames_per_gather": xf}
-                if rank == 0 and not ok:
-                    raise SystemExit("extra workload %s (%s): the composite differs from the single-GPU frame" % (name, share))
-                if share == "equal":
-                    extra[name] = res
-                else:  # the same with rank 0 drawing no tiles
-                    extra[name][share] = {k: res[k] for k in ("render_only_ms", "render_plus_gather_ms", "composite_equals_one_gpu_frame")}
-                del ecb
-            del one
-            # the summary the scaling curve is read from: per frame, the better of the two shares of rank 0
-            best = min([("equal", extra[name])] + ([("none", extra[name]["rank0_idle"])] if "rank0_idle" in extra[name] else []),
-                       key=lambda sv: sv[1]["render_plus_gather_ms"])
-            scaling_workloads[name] = {
-                "one_gpu_ms": one_ms, "render_only_ms": best[1]["render_only_ms"],
-                "render_plus_gather_ms": best[1]["render_plus_gather_ms"], "root_share": best[0], "frames_per_gather": xf,
-                "speedup_over_one_gpu": one_ms / best[1]["render_plus_gather_ms"], "n_gpus": world}
-
     if world > 1 and rank == 0:
         # the composite must equal the same frame rendered by this rank alone
         alone = torch.empty(3, h * w, dtype=torch.int32, device="cuda")
@@ -838,6 +734,140 @@ def main():
         # cannot be read inside this process), or None
         result["roofline"]["valu"] = pmc_valu(args.workload, world, kernel_name.split("+")[-1])
         valu_bound = bool(ao_rays) or spp >= 4  # occlusion rays and many samples per pixel: vector arithmetic, not stores
+
+    # Several ranks: the headline frame is bound by rank 0's own stores (every pixel of every frame is written into
+    # rank 0's HBM whatever N is), so sharding cannot pay there; these short passes (not part of `value`) time the
+    # timed workload and the two heavier ones the same way, as a stream of frames in groups of `xf` per submission
+    # and per gather on two buffer sets: the sharded draws alone, the draws plus the composite, and the whole frames
+    # on one GPU (rank 0 alone on two frame slots, the others idle); per frame, max over ranks.
+    extra, scaling_workloads = {}, {}
+    if world > 1 and sparse and not args.no_extra_workloads:
+        # These passes come after the timed region and must not cost its result: if a rank is still in them after
+        # --extras-watchdog-seconds, rank 0 prints the line it has, with a note, and every rank ends.
+        def extras_give_up():
+            sys.stderr.write("bench.py: rank %d still in the passes over the heavier workloads after %g s; ending without them\n"
+                             % (rank, args.extras_watchdog_seconds))
+            if rank == 0:
+                result["extra_workloads_error"] = ("a rank was still in the passes over the heavier workloads after %g s; "
+                                                   "they were given up, the timed region before them was complete"
+                                                   % args.extras_watchdog_seconds)
+                if extra:
+                    result["extra_workloads"] = extra
+                    result["scaling_workloads"] = scaling_workloads
+                print(json.dumps(result), flush=True)
+            sys.stderr.flush()
+            os._exit(0)
+
+        extras_watchdog = None
+        if args.extras_watchdog_seconds > 0:
+            import threading
+            extras_watchdog = threading.Timer(args.extras_watchdog_seconds, extras_give_up)
+            extras_watchdog.daemon = True
+            extras_watchdog.start()
+        rehearsal = args.backend != "nccl"  # ranks sharing one GPU: enough frames to see that it works
+
+        def timed(body, n, frames_each):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_0 = time.perf_counter()
+            for i in range(n):
+                body(i)
+            ctx.frames_join()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t_0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt[0]) / (n * frames_each) * 1e3
+
+        trace_on = bool(os.environ.get("INV_BENCH_TRACE"))
+
+        def trace(*what):  # where a rank is, for a run that has to be looked into
+            if trace_on:
+                print("bench.py trace: rank %d" % rank, *what, file=sys.stderr, flush=True)
+
+        names = [args.workload] + [n_ for n_ in ("bunny_4k_16spp", "bunny_1080p_ao64_closeup") if n_ != args.workload]
+        for name in names:
+            trace(name, "begin")
+            xw = WORKLOADS[name]
+            if xw.get("instances_side", 1) != side or xw.get("turntable"):
+                continue  # another scene than the one built
+            ew, eh = xw["width"], xw["height"]
+            ecam = R.camera_reference(ew, eh)
+            if side > 1:
+                ecam = common.grid_camera(ecam, side)
+            if "view_translation" in xw:
+                ecam.view[12], ecam.view[13], ecam.view[14] = xw["view_translation"]
+            kw = dict(spp=xw["spp"], flags=xw["flags"], ao_rays=xw.get("ao_rays", 0))
+            heavy = bool(kw["ao_rays"]) or ew * eh * kw["spp"] > 1 << 26
+            xf = (2 if rehearsal else 4) if heavy else (4 if rehearsal else 8)  # frames per group
+            n_x = 2 if rehearsal else (6 if heavy else 24)                      # groups timed
+            # the whole frames on one GPU: rank 0 alone, groups of xf frames on two frame slots in turn
+            eprm = R.make_params(ew, eh, **kw)
+            one_ms, one = None, None
+            if rank == 0:
+                one = torch.empty(2, xf, 3, eh * ew, dtype=torch.int32, device="cuda")
+                one_batches = [scene.make_batch([ecam] * xf, [eprm] * xf,
+                                                [tuple(one[j, u, p_].data_ptr() for p_ in range(3)) for u in range(xf)])
+                               for j in range(2)]
+
+            # (Ranks that share one GPU, occlusion rays: on one slot.  With a second process on the device, rank 0's
+            # occlusion frames on two slots at once have now and then never completed -- one run in seven, only in
+            # this pass, never with one process per GPU or with one process alone, 40 fresh processes and 900 frames
+            # in tools/ao_two_slots_probe.py -- and a rehearsal's times mean nothing anyway.)
+            one_slot = rehearsal and bool(kw["ao_rays"])
+
+            def alone(i):
+                if rank == 0:
+                    scene.render_batch(one_batches[i % 2], 0 if one_slot else i % 2)
+
+            alone(0)
+            alone(1)
+            trace(name, "one GPU: warmed")
+            one_ms = timed(alone, n_x, xf)
+            trace(name, "one GPU: timed")
+            for share, share_flag in [("equal", 0)] + ([("rank0_idle", R.ROOT_IDLE)] if world >= 3 else []):
+                ecb = RD.SparseCompositeBatch(scene, ecam, ew, eh, rank, world, frames=xf, sets=2, tile=32, comm=comm,
+                                              **dict(kw, flags=kw["flags"] | share_flag))
+
+                def draws(i):
+                    ecb.render(i % 2, xf)
+
+                def both(i):
+                    ecb.render(i % 2, xf)
+                    composite_group(ecb, i % 2, xf)
+
+                trace(name, share, "composite made")
+                for i in range(2):
+                    both(i)
+                render_ms = timed(draws, n_x, xf)
+                trace(name, share, "draws timed")
+                both_ms = timed(both, n_x, xf)
+                trace(name, share, "draws + composite timed")
+                both(0)
+                ctx.frames_join()
+                torch.cuda.synchronize()
+                ok = all(bool(torch.equal(one[0, 0], ecb.frames[0][u])) for u in range(xf)) if rank == 0 else True
+                res = {"render_only_ms": render_ms, "render_plus_gather_ms": both_ms, "one_gpu_ms": one_ms,
+                       "composite_equals_one_gpu_frame": ok, "frames_timed": n_x * xf, "frames_per_gather": xf}
+                if rank == 0 and not ok:
+                    raise SystemExit("extra workload %s (%s): the composite differs from the single-GPU frame" % (name, share))
+                if share == "equal":
+                    extra[name] = res
+                else:  # the same with rank 0 drawing no tiles
+                    extra[name][share] = {k: res[k] for k in ("render_only_ms", "render_plus_gather_ms", "composite_equals_one_gpu_frame")}
+                del ecb
+            del one
+            # the summary the scaling curve is read from: per frame, the better of the two shares of rank 0
+            best = min([("equal", extra[name])] + ([("none", extra[name]["rank0_idle"])] if "rank0_idle" in extra[name] else []),
+                       key=lambda sv: sv[1]["render_plus_gather_ms"])
+            scaling_workloads[name] = {
+                "one_gpu_ms": one_ms, "render_only_ms": best[1]["render_only_ms"],
+                "render_plus_gather_ms": best[1]["render_plus_gather_ms"], "root_share": best[0], "frames_per_gather": xf,
+                "speedup_over_one_gpu": one_ms / best[1]["render_plus_gather_ms"], "n_gpus": world}
+
+        if extras_watchdog is not None:
+            extras_watchdog.cancel()
+
+    if rank == 0:
         if extra:
             result["extra_workloads"] = extra
             result["scaling_workloads"] = scaling_workloads

@@ -52,6 +52,16 @@ def test_bench_with_several_ranks_on_one_gpu(nranks, extra):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(180)
+def test_bench_keeps_the_timed_result_when_the_passes_after_it_are_given_up():
+    """The passes over the heavier workloads follow the timed region; a rank that is still in them when their own
+    time limit ends (here: at once) must not cost the line: it is printed with a note and every rank ends well."""
+    r = _run(2, "--extras-watchdog-seconds", "0.02")
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["config"]["hit_pixels"] == 25139
+    assert "given up" in r["extra_workloads_error"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
 @pytest.mark.parametrize("nranks,frames,steps,warmup", [(2, 4, 19, 9), (3, 8, 20, 3), (2, 1, 3, 1)])
 def test_bench_grouped_composite_on_one_gpu(nranks, frames, steps, warmup):
     """Groups of `frames` frames per submission and gather, alternating between two buffer sets, with short last
