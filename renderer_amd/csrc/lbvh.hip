@@ -47,14 +47,21 @@ __global__ __launch_bounds__(1024) void k_bounds_final(const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // 2. Morton keys: 21 bits per axis of the box centre, x in the highest interleaved position
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t expand21(uint32_t v) {
-    uint64_t x = v & 0x1fffffu;
-    x = (x | x << 32) & 0x1f00000000ffffull;
-    x = (x | x << 16) & 0x1f0000ff0000ffull;
-    x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
+// Bit j of an 11-bit value to bit 3 j of a 32-bit word.
+__device__ __forceinline__ uint32_t spread11(uint32_t v) {
+    v = (v | (v << 16)) & 0x070000FFu;
+    v = (v | (v << 8)) & 0x0700F00Fu;
+    v = (v | (v << 4)) & 0x430C30C3u;
+    v = (v | (v << 2)) & 0x49249249u;
+    return v;
+}
+// The key of a cell (21 bits per axis): bit i of x at bit 3 i + 2, of y at 3 i + 1, of z at 3 i.  Made as two 32-bit
+// words (the key's low word holds bits 0-10 of z and y and bits 0-9 of x), a third of the instructions of shifting
+// and masking 64-bit values.
+__device__ __forceinline__ uint64_t morton63(uint32_t x, uint32_t y, uint32_t z) {
+    const uint32_t lo = spread11(z & 0x7FFu) | (spread11(y & 0x7FFu) << 1) | (spread11(x & 0x3FFu) << 2);
+    const uint32_t hi = spread11(x >> 10) | (spread11(z >> 11) << 1) | (spread11(y >> 11) << 2);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 __device__ __forceinline__ uint32_t grid21(float c, float lo, float ext) {
@@ -69,38 +76,52 @@ __device__ __forceinline__ uint32_t grid21(float c, float lo, float ext) {
 // floats: assemble_record), which saves reading 48 bytes per triangle.
 // A workgroup makes the keys of one tile of the sort (kSortTile triangles) and counts their digits of the sort's first
 // pass on the way: that pass then needs no histogram kernel of its own (`counts` as k_sort_hist leaves them).
-__global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ T, MeshSource mesh, uint32_t n,
-                                                const float* __restrict__ bbox, uint64_t* __restrict__ keys,
-                                                uint32_t* __restrict__ vals, int shift, uint32_t ntiles,
-                                                uint32_t* __restrict__ counts) {
+constexpr int kMortonThreads = 1024; // a workgroup per sort tile: two triangles per lane
+__global__ __launch_bounds__(kMortonThreads) void k_morton(const float4* __restrict__ T, MeshSource mesh, uint32_t n,
+                                                           const float* __restrict__ bbox, uint64_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ vals, int shift, uint32_t ntiles,
+                                                           uint32_t* __restrict__ counts) {
     __shared__ uint32_t hist[256];
-    hist[threadIdx.x] = 0;
+    // (tile t writes counter t of each of the 256 digit rows: neighbouring tiles on one XCD fill whole lines)
+    const uint32_t tile = xcd_block(ntiles);
+    if (tile >= ntiles) return; // block-uniform
+    if (threadIdx.x < 256u) hist[threadIdx.x] = 0;
     __syncthreads();
     // one grid step for all three axes (the largest extent): cubic cells, whatever the shape of the scene -- with a
     // step per axis a flat scene (a grid of instances in a plane) gets cells that are thin slabs, and consecutive keys
     // then walk around an instance instead of across a patch of its surface
     const float ex = fmaxf(bbox[3] - bbox[0], fmaxf(bbox[4] - bbox[1], bbox[5] - bbox[2]));
-    const uint32_t tile = blockIdx.x;
-    for (uint32_t r = 0; r < (uint32_t)kSortItems; r++) {
-        const uint32_t i = tile * (uint32_t)kSortTile + r * 256u + threadIdx.x;
-        if (i >= n) break;
-        float4 ra, rb, rc;
-        if (mesh.xyzw) { // (the same for every lane)
-            assemble_record(mesh, i, ra, rb, rc);
-        } else {
-            ra = T[3 * (size_t)i], rb = T[3 * (size_t)i + 1], rc = T[3 * (size_t)i + 2];
-        }
+    // What a triangle needs from memory comes in three dependent steps (indices, vertices, translation), and five
+    // million triangles are only 2 484 tiles: two triangles per lane, both in flight at once, instead of eight one after
+    // the other.  (The kernel's time is mostly its arithmetic: without the gathers it takes 26 us of 33, without the
+    // stores 29, without the counts 31.)
+    constexpr uint32_t kPer = (uint32_t)kSortTile / (uint32_t)kMortonThreads;
+    static_assert(kPer * kMortonThreads == kSortTile, "a tile is a whole number of triangles per lane");
+    uint32_t g[kPer];
+    float4 ra[kPer], rb[kPer], rc[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; u++) g[u] = min(tile * (uint32_t)kSortTile + u * (uint32_t)kMortonThreads + threadIdx.x, n - 1u);
+    if (mesh.xyzw) { // (the same for every lane)
+        assemble_records<(int)kPer>(mesh, g, ra, rb, rc);
+    } else {
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) ra[u] = T[3 * (size_t)g[u]], rb[u] = T[3 * (size_t)g[u] + 1], rc[u] = T[3 * (size_t)g[u] + 2];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; u++) {
+        const uint32_t i = tile * (uint32_t)kSortTile + u * (uint32_t)kMortonThreads + threadIdx.x;
         float lo[3], hi[3];
-        tri_box(ra, rb, rc, lo, hi);
+        tri_box(ra[u], rb[u], rc[u], lo, hi);
         const float cx = (lo[0] + hi[0]) * 0.5f, cy = (lo[1] + hi[1]) * 0.5f, cz = (lo[2] + hi[2]) * 0.5f;
-        const uint64_t key = (expand21(grid21(cx, bbox[0], ex)) << 2) | (expand21(grid21(cy, bbox[1], ex)) << 1) |
-                             expand21(grid21(cz, bbox[2], ex));
-        keys[i] = key;
-        vals[i] = i;
-        atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+        const uint64_t key = morton63(grid21(cx, bbox[0], ex), grid21(cy, bbox[1], ex), grid21(cz, bbox[2], ex));
+        if (i < n) {
+            keys[i] = key;
+            vals[i] = i;
+            atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
-    counts[threadIdx.x * ntiles + tile] = hist[threadIdx.x];
+    if (threadIdx.x < 256u) counts[threadIdx.x * ntiles + tile] = hist[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1445,7 +1466,7 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
     uint64_t* kout = (steps & 1) ? sc.morton : keys_alt;
     uint32_t* vout = (steps & 1) ? sc.order : vals_alt;
     static_assert(kSortThreads == 256, "k_morton counts the digits of one sort tile per workgroup");
-    hipLaunchKernelGGL(k_morton, dim3(ntiles), blk, 0, s, T0, mesh, n, d_bbox, kin, vin, sort_shift, ntiles, counts);
+    hipLaunchKernelGGL(k_morton, dim3(xcd_grid(ntiles)), dim3(kMortonThreads), 0, s, T0, mesh, n, d_bbox, kin, vin, sort_shift, ntiles, counts);
     for (int pass = sort_shift / 8; pass < 8; pass++) {
         const int shift = 8 * pass;
         if (pass != sort_shift / 8) // (the first pass's digits were counted with the keys)

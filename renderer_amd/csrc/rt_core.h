@@ -207,6 +207,42 @@ __device__ __forceinline__ void assemble_record(const MeshSource& m, uint64_t g,
     rc = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, c.z);
 }
 
+// The same for N triangles at once (their ids below 2^32): what a stage needs from memory -- the indices, then the
+// vertices and the translations -- is asked for together, so a lane waits three times for N triangles, not 3 N times.
+template <int N>
+__device__ __forceinline__ void assemble_records(const MeshSource& m, const uint32_t (&g)[N], float4 (&ra)[N], float4 (&rb)[N],
+                                                 float4 (&rc)[N]) {
+    uint32_t inst[N], i0[N], i1[N], i2[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        inst[u] = g[u] / m.base_ntri;
+        const uint32_t k = g[u] % m.base_ntri;
+        i0[u] = m.idx[3 * (size_t)k + 0], i1[u] = m.idx[3 * (size_t)k + 1], i2[u] = m.idx[3 * (size_t)k + 2];
+    }
+    float t[N][3];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        t[u][0] = t[u][1] = t[u][2] = 0.0f;
+        if (m.translations) // (the same for every lane)
+            t[u][0] = m.translations[3 * (size_t)inst[u] + 0], t[u][1] = m.translations[3 * (size_t)inst[u] + 1],
+            t[u][2] = m.translations[3 * (size_t)inst[u] + 2];
+    }
+    float4 a[N], b[N], c[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) a[u] = m.xyzw[i0[u]], b[u] = m.xyzw[i1[u]], c[u] = m.xyzw[i2[u]];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        if (m.translations) {
+            a[u].x = a[u].x + t[u][0], a[u].y = a[u].y + t[u][1], a[u].z = a[u].z + t[u][2];
+            b[u].x = b[u].x + t[u][0], b[u].y = b[u].y + t[u][1], b[u].z = b[u].z + t[u][2];
+            c[u].x = c[u].x + t[u][0], c[u].y = c[u].y + t[u][1], c[u].z = c[u].z + t[u][2];
+        }
+        ra[u] = make_float4(a[u].x, a[u].y, a[u].z, __uint_as_float(g[u]));
+        rb[u] = make_float4(b[u].x - a[u].x, b[u].y - a[u].y, b[u].z - a[u].z, b[u].z);
+        rc[u] = make_float4(c[u].x - a[u].x, c[u].y - a[u].y, c[u].z - a[u].z, c[u].z);
+    }
+}
+
 // Box of a triangle record as stored (A, B = v1 - A, C = v2 - A): the corners are A, A + B, A + C, not the vertices
 // they were made from.
 __device__ __forceinline__ void tri_box(const float4& A, const float4& B, const float4& C, float lo[3], float hi[3]) {
