@@ -137,11 +137,12 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __re
     hist[threadIdx.x] = 0;
     __syncthreads();
     uint32_t base = tile * kSortTile;
+    uint64_t key[kSortItems]; // (all asked for at once, from places that exist: loads under a condition wait for each other)
 #pragma unroll
-    for (int r = 0; r < kSortItems; r++) {
-        uint32_t i = base + r * kSortThreads + threadIdx.x;
-        if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
-    }
+    for (int r = 0; r < kSortItems; r++) key[r] = keys[min(base + r * kSortThreads + threadIdx.x, n - 1u)];
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++)
+        if (base + r * kSortThreads + threadIdx.x < n) atomicAdd(&hist[(uint32_t)(key[r] >> shift) & 255u], 1u);
     __syncthreads();
     counts[threadIdx.x * ntiles + tile] = hist[threadIdx.x];
 }
@@ -242,21 +243,29 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
     uint64_t key[kSortItems];
     uint32_t val[kSortItems], rank[kSortItems];
     uint32_t* mine = s_wave[wave];
+    // (all of a lane's keys are asked for at once, from places that exist whether the key does or not: loads under a
+    // condition each wait for the one before)
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t j = min(wave * (kSortItems * 64u) + r * 64u + lane, tile_n - 1u);
+        key[r] = keys_in[base + j], val[r] = vals_in[base + j];
+    }
 #pragma unroll
     for (int r = 0; r < kSortItems; r++) {
         const uint32_t j = wave * (kSortItems * 64u) + r * 64u + lane;
         const bool valid = j < tile_n;
-        key[r] = valid ? keys_in[base + j] : ~0ull;
-        val[r] = valid ? vals_in[base + j] : 0u;
+        if (!valid) key[r] = ~0ull, val[r] = 0u;
         const uint32_t digit = (uint32_t)(key[r] >> shift) & 255u;
-        // lanes of this wave holding the same digit
-        uint64_t same = __ballot(valid);
+        // lanes of this wave holding the same digit: per bit of the digit, the lanes whose bit differs from this lane's
+        // are the ballot of the bit, complemented where this lane's bit is set (an exclusive or with 0 or ~0)
+        uint32_t dlo = 0, dhi = 0;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const bool bit = (digit >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)digit, b, 1); // ~0 if the bit is set, else 0
+            const uint64_t bal = __ballot(m != 0u);
+            dlo |= (uint32_t)bal ^ m, dhi |= (uint32_t)(bal >> 32) ^ m;
         }
+        const uint64_t same = ~(((uint64_t)dhi << 32) | dlo) & __ballot(valid);
         const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
         // a wave's LDS accesses execute in program order: every lane reads the count, then one lane per digit adds
         const uint32_t earlier = mine[digit];
@@ -344,17 +353,33 @@ __global__ __launch_bounds__(256) void k_sort_runs(const uint64_t* __restrict__ 
     // a dozen or more of them where cells hold several triangles
     __shared__ uint64_t s_k[256 + 2 * kRunMax];
     const uint32_t base = blockIdx.x * 256u, t = threadIdx.x, i = base + t;
+    const uint32_t v = i < n ? vin[i] : 0u; // (asked for now, wanted at the end)
     for (uint32_t j = t; j < 256u + 2u * kRunMax; j += 256u) {
         const int64_t g = (int64_t)base - (int64_t)kRunMax + j;
         s_k[j] = g >= 0 && g < (int64_t)n ? kin[g] : 0ull; // (places outside the array are never looked at)
     }
     __syncthreads();
-    if (i >= n) return;
-    const uint32_t p = t + kRunMax; // key i sits at s_k[p]
+    const bool valid = i < n;
+    const uint32_t lane = t & 63u, p = t + kRunMax; // key i sits at s_k[p]
     const uint64_t k = s_k[p], hi = k >> shift;
-    uint32_t a = i, b = i + 1u;
-    while (a > 0u && i - a < kRunMax && (s_k[p - (i - a) - 1u] >> shift) == hi) a--;
-    while (b < n && b - i <= kRunMax && (s_k[p + (b - i)] >> shift) == hi) b++; // (b - i counts key i itself)
+    // Where the key's run begins and ends: first within the wave, from two ballots (does the key before, the key after,
+    // belong to the same run?) -- no lane looks further than its neighbours unless its run reaches the wave's first or
+    // last lane, and then it goes on from there, step by step.
+    const bool ep = valid && i > 0u && (s_k[p - 1u] >> shift) == hi;
+    const bool en = valid && i + 1u < n && (s_k[p + 1u] >> shift) == hi;
+    const uint64_t mp = __ballot(ep), mn = __ballot(en);
+    const uint64_t zp = ~mp & ((2ull << lane) - 1ull); // lanes up to this one whose run begins with them
+    const uint64_t zn = ~mn & (~0ull << lane);         // lanes from this one on whose run ends with them
+    uint32_t a = i - lane, b = i + (64u - lane); // (the wave's first key; the key after its last)
+    if (zp)
+        a = i - (lane - (63u - (uint32_t)__clzll((long long)zp)));
+    else
+        while (a > 0u && i - a < kRunMax && (s_k[p - (i - a) - 1u] >> shift) == hi) a--;
+    if (zn)
+        b = i + ((uint32_t)__ffsll((long long)zn) - 1u - lane) + 1u;
+    else
+        while (b < n && b - i <= kRunMax && (s_k[p + (b - i)] >> shift) == hi) b++; // (b - i counts key i itself)
+    if (!valid) return;
     uint32_t at = i;
     if (b - a > kRunMax) {
         *too_long = 1u; // (every thread that comes here writes the same value)
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(256) void k_sort_runs(const uint64_t* __restrict__ 
         }
         at = a + before;
     }
-    kout[at] = k, vout[at] = vin[i];
+    kout[at] = k, vout[at] = v;
 }
 
 // ------------------------------------------------------------------------------------------
