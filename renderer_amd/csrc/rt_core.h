@@ -304,8 +304,13 @@ __device__ __forceinline__ uint32_t srgb8(float x, const float* T) {
     const float s = x <= 0.0031308f ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.4f)) - 0.055f;
     int k = (int)(255.0f * s + 0.5f);
     k = k < 1 ? 1 : (k > 254 ? 254 : k);
-    while (x < T[k]) k--;      // stops at k = 1 at the latest: x >= T[1]
-    while (x >= T[k + 1]) k++; // stops at k = 254 at the latest: x < T[255]
+    // (both neighbours of the estimate are asked for together: one wait where the estimate is right, which is the rule)
+    const float t0 = T[k], t1 = T[k + 1];
+    if (x < t0) {
+        do k--; while (x < T[k]); // stops at k = 1 at the latest: x >= T[1]
+    } else if (x >= t1) {
+        do k++; while (x >= T[k + 1]); // stops at k = 254 at the latest: x < T[255]
+    }
     return (uint32_t)k;
 }
 
@@ -451,7 +456,8 @@ __device__ __forceinline__ void ao_push(const AoK& ao, bool push, const float o[
 // colour attachment store: sRGB encode, optional invert post-pass, B,G,R,A byte order
 // unless INV_RGBA (src/invert.cpp:519)
 __device__ __forceinline__ uint32_t pack_pixel(uint32_t flags, float r, float g, float b, const float* T = kSrgbT) {
-    uint32_t R = srgb8(r, T), G = (g == r) ? R : srgb8(g, T), B = srgb8(b, T);
+    const uint32_t R0 = srgb8(r, T), G0 = (g == r) ? R0 : srgb8(g, T); // (a grey pixel: one lookup)
+    uint32_t R = R0, G = G0, B = (b == r) ? R0 : (b == g) ? G0 : srgb8(b, T);
     if (flags & INV_INVERT) R = 255u - R, G = 255u - G, B = 255u - B;
     uint32_t lo = (flags & INV_RGBA) ? R : B;
     uint32_t hi = (flags & INV_RGBA) ? B : R;

@@ -1939,14 +1939,15 @@ __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, MeshSource m
                 slot[j] = hit[j] && !mesh.xyzw ? slot_of[(uint32_t)keys[j0 + j]] : 0u;
             }
             float4 A[G], B[G], C[G];
+            if (mesh.xyzw) { // (the same for every lane) the winners assembled again from the cached mesh, together:
+                uint32_t ids[G]; // a pixel without a hit takes triangle 0 along, which nothing looks at
 #pragma unroll
-            for (int j = 0; j < G; j++)
-                if (hit[j]) {
-                    if (mesh.xyzw) // (the same for every lane) the winner assembled again from the cached mesh
-                        assemble_record(mesh, (uint32_t)keys[j0 + j], A[j], B[j], C[j]);
-                    else
-                        A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]];
-                }
+                for (int j = 0; j < G; j++) ids[j] = hit[j] ? (uint32_t)keys[j0 + j] : 0u;
+                assemble_records<G>(mesh, ids, A, B, C);
+            } else {
+#pragma unroll
+                for (int j = 0; j < G; j++) A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]]; // (slot 0 without a hit)
+            }
 #pragma unroll
             for (int j = 0; j < G; j++) {
                 float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
