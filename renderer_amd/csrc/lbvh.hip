@@ -33,9 +33,11 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks) {
 static inline uint32_t xcd_grid(uint32_t nblocks) { return ((nblocks + 7u) >> 3) * 8u; }
 
 // The scene bounds from their first stage: partial[block][6] = lo xyz, hi xyz over a share of the triangles, which
-// the assembly kernel leaves on its way (no float atomics).
+// the assembly kernel leaves on its way (no float atomics).  On the side it clears the build's counters (`nzero` words
+// from `zero`): a fill of their own would be one more launch, and a launch of anything is 4 us behind the one before.
 __global__ __launch_bounds__(1024) void k_bounds_final(const float* __restrict__ partial, uint32_t nblocks,
-                                                       float* __restrict__ bbox) {
+                                                       float* __restrict__ bbox, uint32_t* __restrict__ zero, uint32_t nzero) {
+    for (uint32_t i = threadIdx.x; i < nzero; i += 1024u) zero[i] = 0u;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t b = threadIdx.x; b < nblocks; b += 1024u) {
 #pragma unroll
@@ -1479,9 +1481,8 @@ static hipError_t build_lbvh_with(hipStream_t s, DeviceScene& sc, Arena& keep, A
 
     const float4* T0 = (const float4*)records;
     const dim3 blk(256), grid_n((n + 255) / 256);
-    HIP_RET(hipMemsetAsync(words, 0, build_words_for(n) * 4, s));
     uint32_t* const too_long = words + kWUnsorted;
-    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(1024), 0, s, bounds, bounds_blocks, d_bbox);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(1024), 0, s, bounds, bounds_blocks, d_bbox, words, (uint32_t)build_words_for(n));
     // 63 significant key bits -> 8 passes of 8 bits, or the upper digits only and k_sort_runs for the rest.  The
     // passes and the run kernel go from one pair of arrays to the other; the keys start in the pair that makes them
     // end in sc.morton / sc.order.
