@@ -541,7 +541,7 @@ int inv_scene_build_instanced(inv_ctx* ctx, const inv_mesh* mesh, const float* t
         if ((e = launch_assemble(ctx->stream, d.xyzw, nv, d.idx, base_ntri, d_tr, ninst, A0, B0, C0, tree ? 3u : 1u, bounds)) != hipSuccess)
             return bail(e, "assemble kernel");
         if (ctx->build_sort_ntri != d.ntri) ctx->build_sort_hint = 0, ctx->build_sort_ntri = d.ntri;
-        const MeshSource mesh_src = {cached_mesh ? (const float4*)d.xyzw : nullptr, d.idx, d_tr, base_ntri, ninst};
+        const MeshSource mesh_src = mesh_source(cached_mesh ? (const float4*)d.xyzw : nullptr, d.idx, d_tr, base_ntri, ninst);
         d.translations = d_tr, d.base_ntri = base_ntri, d.ninst = ninst, d.mesh_cached = cached_mesh;
         if ((e = build_lbvh(ctx->stream, d, keep, scratch, records, bounds, mesh_src, &ctx->build_sort_hint)) != hipSuccess) return bail(e, "LBVH build");
     }

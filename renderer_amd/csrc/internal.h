@@ -127,7 +127,18 @@ struct MeshSource {
     const uint32_t* idx;
     const float* translations; // xyz per instance, or null
     uint32_t base_ntri, ninst;
+    // g / base_ntri for any 32-bit g without a division (T. Granlund, P. Montgomery, "Division by Invariant Integers
+    // using Multiplication", 1994, figure 4.1): q = mulhi(div_magic, g); (q + ((g - q) >> div_sh1)) >> div_sh2
+    uint32_t div_magic, div_sh1, div_sh2;
 };
+inline MeshSource mesh_source(const float4* xyzw, const uint32_t* idx, const float* translations, uint32_t base_ntri, uint32_t ninst) {
+    MeshSource m = {xyzw, idx, translations, base_ntri, ninst, 1u, 0u, 0u};
+    const uint32_t d = base_ntri ? base_ntri : 1u;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++; // ceil(log2 d)
+    m.div_magic = (uint32_t)((((1ull << l) - d) << 32) / d + 1u), m.div_sh1 = l < 1u ? l : 1u, m.div_sh2 = l > 0u ? l - 1u : 0u;
+    return m;
+}
 // Triangle g's three 16-byte items go to A[g * stride], B[g * stride], C[g * stride] (in float4 units): stride 1
 // fills three arrays, stride 3 with B = A + 4 floats and C = A + 8 floats one array of 48-byte records.
 // `bounds` (or null): bounds_blocks_for(triangles) entries of six floats, the box of a share of the triangles each

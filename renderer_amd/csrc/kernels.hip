@@ -82,7 +82,7 @@ hipError_t launch_assemble(hipStream_t s, const float* xyzw, uint32_t nv, const 
     if (total == 0) return hipSuccess;
     // (with bounds: as many workgroups as the bounds have first-stage entries; without, one triangle per lane)
     const unsigned blocks = bounds ? bounds_blocks_for((uint32_t)total) : (unsigned)((total + 255) / 256);
-    const MeshSource m = {(const float4*)xyzw, idx, translations, base_ntri, ninst};
+    const MeshSource m = mesh_source((const float4*)xyzw, idx, translations, base_ntri, ninst);
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, m, (float4*)A, (float4*)B, (float4*)C, stride, bounds);
     return hipGetLastError();
 }

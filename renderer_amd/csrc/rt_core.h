@@ -187,11 +187,17 @@ __device__ __forceinline__ void mt_test(const FrameK& f, const Ray& r, const flo
     best.slot = slot;
 }
 
+// g / base_ntri (see MeshSource)
+__device__ __forceinline__ uint32_t mesh_instance_of(const MeshSource& m, uint32_t g) {
+    const uint32_t q = __umulhi(m.div_magic, g);
+    return (q + ((g - q) >> m.div_sh1)) >> m.div_sh2;
+}
+
 // Primitive assembly of triangle g: instance g / base_ntri of template triangle g % base_ntri, as the three 16-byte
 // items of its record (A with the primitive id, B = v1 - A, C = v2 - A, each with the vertex's own z in w).  Every
 // kernel that wants the record without reading it back gets the same floats from here.
 __device__ __forceinline__ void assemble_record(const MeshSource& m, uint64_t g, float4& ra, float4& rb, float4& rc) {
-    const uint32_t inst = (uint32_t)(g / m.base_ntri), k = (uint32_t)(g % m.base_ntri);
+    const uint32_t inst = mesh_instance_of(m, (uint32_t)g), k = (uint32_t)g - inst * m.base_ntri; // (g is below 2^32)
     float4 a = m.xyzw[m.idx[3 * (size_t)k + 0]];
     float4 b = m.xyzw[m.idx[3 * (size_t)k + 1]];
     float4 c = m.xyzw[m.idx[3 * (size_t)k + 2]];
@@ -215,8 +221,8 @@ __device__ __forceinline__ void assemble_records(const MeshSource& m, const uint
     uint32_t inst[N], i0[N], i1[N], i2[N];
 #pragma unroll
     for (int u = 0; u < N; u++) {
-        inst[u] = g[u] / m.base_ntri;
-        const uint32_t k = g[u] % m.base_ntri;
+        inst[u] = mesh_instance_of(m, g[u]);
+        const uint32_t k = g[u] - inst[u] * m.base_ntri;
         i0[u] = m.idx[3 * (size_t)k + 0], i1[u] = m.idx[3 * (size_t)k + 1], i2[u] = m.idx[3 * (size_t)k + 2];
     }
     float t[N][3];

@@ -2400,8 +2400,8 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
     if (vis && scatter_wanted(f, sc, out)) {
         // a mesh that the caches hold: the resolve pass assembles the winners from it instead of looking them up in the
         // sorted arrays (INV_MESH_DRAW=0 in the environment: never; for measurements)
-        const MeshSource mesh = {sc.mesh_cached && mesh_draw_enabled() ? (const float4*)sc.xyzw : nullptr, sc.idx,
-                                 sc.translations, sc.base_ntri, sc.ninst};
+        const MeshSource mesh = mesh_source(sc.mesh_cached && mesh_draw_enabled() ? (const float4*)sc.xyzw : nullptr, sc.idx,
+                                                 sc.translations, sc.base_ntri, sc.ninst);
         // (nothing to try when the scene lies outside the frame: the resolve pass then stores clear values only)
         if (f.rx1 > f.rx0 && f.ry1 > f.ry0)
             hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 256u * kScatterPerLane - 1u) / (256u * kScatterPerLane)), dim3(256), 0, s, f, (const float4*)sc.triA,
