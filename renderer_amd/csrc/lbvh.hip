@@ -681,28 +681,33 @@ __device__ __forceinline__ float max_raw(float a, float b) {
 // slots 16-byte aligned), without waiting for the swap's answer in between: returns what the flag held.  Written out
 // because the order of the five is the point -- left to itself the compiler moves the reads to where their values are
 // used, behind the wait for the answer.  (The low half of an LDS pointer is the offset the instructions take.)
+// A slot's two halves lie HALF bytes apart (an array of first halves, then one of second halves: lanes that take
+// neighbouring slots then touch neighbouring 16-byte pieces, where 32-byte slots made every access a two-way bank
+// conflict).
+template <int HALF>
 __device__ __forceinline__ uint32_t lds_put_swap_then_read(float4* mine, v4f m0, v4f m1, uint32_t* flag, uint32_t word, const float4* slot,
                                                            v4f& s0, v4f& s1) {
     uint32_t other;
     const uint32_t ma = (uint32_t)(uintptr_t)mine, fa = (uint32_t)(uintptr_t)flag, sa = (uint32_t)(uintptr_t)slot;
-    asm volatile("ds_write_b128 %6, %7\n\tds_write_b128 %6, %8 offset:16\n\tds_wrxchg_rtn_b32 %0, %3, %4\n\tds_read_b128 %1, %5\n\t"
-                 "ds_read_b128 %2, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
+    asm volatile("ds_write_b128 %6, %7\n\tds_write_b128 %6, %8 offset:%9\n\tds_wrxchg_rtn_b32 %0, %3, %4\n\tds_read_b128 %1, %5\n\t"
+                 "ds_read_b128 %2, %5 offset:%9\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(other), "=&v"(s0), "=&v"(s1)
-                 : "v"(fa), "v"(word), "v"(sa), "v"(ma), "v"(m0), "v"(m1)
+                 : "v"(fa), "v"(word), "v"(sa), "v"(ma), "v"(m0), "v"(m1), "n"(HALF)
                  : "memory");
     return other;
 }
 // (the same with four more bytes of one's own, `mw` to `mine_w`, and of the sibling's, from `word_at`)
+template <int HALF>
 __device__ __forceinline__ uint32_t lds_put_swap_then_read(float4* mine, v4f m0, v4f m1, uint32_t* mine_w, uint32_t mw, uint32_t* flag,
                                                            uint32_t word, const float4* slot, const uint32_t* word_at, v4f& s0,
                                                            v4f& s1, uint32_t& w) {
     uint32_t other;
     const uint32_t ma = (uint32_t)(uintptr_t)mine, mwa = (uint32_t)(uintptr_t)mine_w, fa = (uint32_t)(uintptr_t)flag,
                    sa = (uint32_t)(uintptr_t)slot, wa = (uint32_t)(uintptr_t)word_at;
-    asm volatile("ds_write_b128 %8, %9\n\tds_write_b128 %8, %10 offset:16\n\tds_write_b32 %11, %12\n\tds_wrxchg_rtn_b32 %0, %4, %5\n\t"
-                 "ds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+    asm volatile("ds_write_b128 %8, %9\n\tds_write_b128 %8, %10 offset:%13\n\tds_write_b32 %11, %12\n\tds_wrxchg_rtn_b32 %0, %4, %5\n\t"
+                 "ds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:%13\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(other), "=&v"(s0), "=&v"(s1), "=&v"(w)
-                 : "v"(fa), "v"(word), "v"(sa), "v"(wa), "v"(ma), "v"(m0), "v"(m1), "v"(mwa), "v"(mw)
+                 : "v"(fa), "v"(word), "v"(sa), "v"(wa), "v"(ma), "v"(m0), "v"(m1), "v"(mwa), "v"(mw), "n"(HALF)
                  : "memory");
     return other;
 }
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
                                                          uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
     // per split g (between the chunk's leaves g and g + 1) the two subtrees that meet there, as they arrive: [2 g] the one
     // that ends at g, [2 g + 1] the one that begins at g + 1; (box lo, height) (box hi, -)
-    __shared__ float4 s_slot[2 * kChunk][2];
+    __shared__ float4 s_slot[2][2 * kChunk]; // ([0]: first halves, [1]: second halves)
     // first the keys of the chunk and of one leaf on either side; then, in the same place, per split: s_flag (0, or what
     // the first child to arrive left: its far end + 1 | the prefix beyond that end + 1 << 16, or kMerged) and, per node
     // made here, by name: s_info (1 << 31 | r << 18 | l << 9 | split)
@@ -793,9 +798,9 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
             if (gp < 0 || gp >= (int)kChunk - 1) break; // the sibling lies in another chunk
             const uint32_t mine = 2u * (uint32_t)gp + (right ? 0u : 1u);
             v4f s0, s1;
-            const uint32_t other = lds_put_swap_then_read(&s_slot[mine][0], lo4, hi4, &s_flag[gp],
+            const uint32_t other = lds_put_swap_then_read<(int)(2 * kChunk * 16)>(&s_slot[0][mine], lo4, hi4, &s_flag[gp],
                                                           ((right ? l : r) + 1u) | ((uint32_t)((right ? dl : dr) + 1) << 16),
-                                                          &s_slot[mine ^ 1u][0], s0, s1);
+                                                          &s_slot[0][mine ^ 1u], s0, s1);
             if (other == 0u) break; // the first to arrive
             lo4.x = min_raw(lo4.x, s0.x), lo4.y = min_raw(lo4.y, s0.y), lo4.z = min_raw(lo4.z, s0.z);
             hi4.x = max_raw(hi4.x, s1.x), hi4.y = max_raw(hi4.y, s1.y), hi4.z = max_raw(hi4.z, s1.z);
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
         leaves = make_uint2(base + l, base + r);
         // (the record -- written below -- is all of the node there is: who asks for child or parent arrays gets them made
         // from the records)
-        const float4 p0 = s_slot[2u * g][0], p1 = s_slot[2u * g][1], q0 = s_slot[2u * g + 1u][0], q1 = s_slot[2u * g + 1u][1];
+        const float4 p0 = s_slot[0][2u * g], p1 = s_slot[1][2u * g], q0 = s_slot[0][2u * g + 1u], q1 = s_slot[1][2u * g + 1u];
         b0[0] = p0.x, b0[1] = p0.y, b0[2] = p0.z, b0[3] = p1.x, b0[4] = p1.y, b0[5] = p1.z;
         b1[0] = q0.x, b1[1] = q0.y, b1[2] = q0.z, b1[3] = q1.x, b1[4] = q1.y, b1[5] = q1.z;
         if (s_delta[l] < 0 && s_delta[r + 1u] < 0) { // the root: one chunk holds it all
@@ -843,13 +848,16 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
     // the wave touch 64 different lines, 16 bytes of each; through LDS (the slots' array, which nobody reads any more:
     // emit_fine's barriers lie in between) a wave's records leave as four instructions of 1 KiB of consecutive bytes each.
     {
+        // (Piece q of record r lies at 4 r + ((q + r / 4) & 3): a lane's four stores are 64 bytes apart from its
+        // neighbours', and without the rotation sixteen lanes would share four of the sixteen 16-byte bank groups; with
+        // it both the stores, a record per lane, and the loads, a piece per lane, take each group once.)
         float4* const stage = (float4*)&s_slot[0][0] + 4u * t; // this lane's record
-        const uint32_t lane = t & 63u;
+        const uint32_t lane = t & 63u, rot = (t >> 2) & 3u;
         const uint64_t mm = __ballot(made);
-        stage[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
-        stage[1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
-        stage[2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
-        stage[3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
+        stage[rot] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+        stage[(1u + rot) & 3u] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+        stage[(2u + rot) & 3u] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+        stage[(3u + rot) & 3u] = make_float4(__uint_as_float(c0), __uint_as_float(c1), __uint_as_float(leaves.x), __uint_as_float(leaves.y));
         // (a wave reads only what it wrote itself, and LDS carries a wave's operations out in order)
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         const float4* const mine = (const float4*)&s_slot[0][0] + 4u * (t - lane); // the wave's 64 records
@@ -857,7 +865,8 @@ __global__ __launch_bounds__(kChunk) void k_build_chunks(const float4* __restric
 #pragma unroll
         for (uint32_t j = 0; j < 4u; j++) {
             const uint32_t piece = j * 64u + lane; // 16-byte piece of the wave's 4 KiB: record piece / 4
-            if ((mm >> (piece >> 2)) & 1ull) out[piece] = mine[piece];
+            const uint32_t r = piece >> 2; // (the wave's first record is a multiple of 64: r / 4 rotates as t / 4 does)
+            if ((mm >> r) & 1ull) out[piece] = mine[4u * r + (((piece & 3u) + (r >> 2)) & 3u)];
         }
     }
     // The tops, in leaf order: the lane that carried a subtree to where it stopped holds it, and the lanes' own leaves
@@ -901,7 +910,7 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
                                                      uint32_t* __restrict__ fine_count, uint32_t fine_cap) {
     // per split g (between items g and g + 1) the two subtrees that meet there, as they arrive: [2 g] the one that ends
     // with item g, [2 g + 1] the one that begins with item g + 1; (box lo, first leaf) (box hi, last leaf), and the height
-    __shared__ float4 s_slot[2 * kLevelItems][2];
+    __shared__ float4 s_slot[2][2 * kLevelItems]; // ([0]: first halves, [1]: second halves)
     __shared__ uint32_t s_sh[2 * kLevelItems];
     __shared__ uint32_t s_nme[kLevelItems];   // per split: the name of the node made there
     // per split: 0, or what the first child to arrive left (its far item + 1 | the prefix beyond that end + 1 << 10), or kMerged
@@ -964,9 +973,9 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
             const uint32_t mine = 2u * (uint32_t)gp + (right ? 0u : 1u);
             v4f s0, s1;
             uint32_t sh;
-            const uint32_t other = lds_put_swap_then_read(&s_slot[mine][0], lo4, hi4, &s_sh[mine], h, &s_flag[gp],
+            const uint32_t other = lds_put_swap_then_read<(int)(2 * kLevelItems * 16)>(&s_slot[0][mine], lo4, hi4, &s_sh[mine], h, &s_flag[gp],
                                                           ((right ? il : ir) + 1u) | ((uint32_t)((right ? dl : dr) + 1) << 10),
-                                                          &s_slot[mine ^ 1u][0], &s_sh[mine ^ 1u], s0, s1, sh);
+                                                          &s_slot[0][mine ^ 1u], &s_sh[mine ^ 1u], s0, s1, sh);
             if (other == 0u) break; // the first to arrive
             lo4.x = min_raw(lo4.x, s0.x), lo4.y = min_raw(lo4.y, s0.y), lo4.z = min_raw(lo4.z, s0.z);
             hi4.x = max_raw(hi4.x, s1.x), hi4.y = max_raw(hi4.y, s1.y), hi4.z = max_raw(hi4.z, s1.z);
@@ -990,7 +999,7 @@ __global__ __launch_bounds__(kLevelThreads) void k_build_level(const float4* __r
         const uint32_t g = tid;
         if (g + 1u < M && s_flag[g] == kMerged) {
             made = 1u;
-            const float4 p0 = s_slot[2u * g][0], p1 = s_slot[2u * g][1], q0 = s_slot[2u * g + 1u][0], q1 = s_slot[2u * g + 1u][1];
+            const float4 p0 = s_slot[0][2u * g], p1 = s_slot[1][2u * g], q0 = s_slot[0][2u * g + 1u], q1 = s_slot[1][2u * g + 1u];
             const float b0[6] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z}, b1[6] = {q0.x, q0.y, q0.z, q1.x, q1.y, q1.z};
             const uint32_t me = s_nme[g], l = __float_as_uint(p0.w), r = __float_as_uint(q1.w);
             const uint32_t gamma = __float_as_uint(p1.w); // last leaf of the left child
