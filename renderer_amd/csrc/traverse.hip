@@ -1744,10 +1744,11 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
         rA[u] = rB[u] = rC[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (k < ntri) rA[u] = TA[k], rB[u] = TB[k], rC[u] = TC[k];
     }
+    bool front[kScatterPerLane];
 #pragma unroll
     for (uint32_t u = 0; u < kScatterPerLane; u++) {
         const uint32_t k = (blockIdx.x * kScatterPerLane + u) * 256u + threadIdx.x;
-        bool front = false;
+        front[u] = false;
         if (k < ntri) {
             // cull BACK (src/invert.cpp:1334).  For a ray from the origin o that meets the triangle's plane at
             // p = o + t d, t > 0, det = e1 . (d x e2) = (p - o) . (e2 x e1) / t, and (p - o) . n is the same for every p
@@ -1760,10 +1761,26 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
             const float tx = f.ox - A.x, ty = f.oy - A.y, tz = f.oz - A.z;
             const float sd = (tx * P0.x + ty * P0.y) + tz * P0.z;
             const float mag = (fabsf(tx * P0.x) + fabsf(ty * P0.y)) + fabsf(tz * P0.z);
-            front = !(sd > 1e-4f * mag);
+            front[u] = !(sd > 1e-4f * mag);
         }
-        const uint32_t at = wave_append(&s_nfront, front, lane);
-        if (front) s_front[at] = k, s_recA[at] = rA[u], s_recB[at] = rB[u], s_recC[at] = rC[u];
+    }
+    {
+        // the wave's places in the list for all its triangles at once: one update of the counter, the lanes ranked by ballot
+        uint64_t mask[kScatterPerLane];
+        uint32_t n = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kScatterPerLane; u++) mask[u] = __ballot(front[u]), n += (uint32_t)__popcll(mask[u]);
+        uint32_t at = 0;
+        if (n) { // (the same for the whole wave)
+            if (lane == 0) at = atomicAdd(&s_nfront, n);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kScatterPerLane; u++) {
+            const uint32_t mine = at + (uint32_t)__popcll(mask[u] & ((1ull << lane) - 1ull));
+            if (front[u]) s_front[mine] = (blockIdx.x * kScatterPerLane + u) * 256u + threadIdx.x, s_recA[mine] = rA[u], s_recB[mine] = rB[u], s_recC[mine] = rC[u];
+            at += (uint32_t)__popcll(mask[u]);
+        }
     }
     __syncthreads();
     const uint32_t nfront = s_nfront;
@@ -1778,22 +1795,27 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
         // matrix, their pixel bounds widened by an eighth of a pixel.  A vertex at or behind the eye's plane (the
         // launcher only takes scenes that lie in front of it) makes the triangle claim the whole frame.
         const float vx[3] = {A.x, A.x + B.x, A.x + C.x}, vy[3] = {A.y, A.y + B.y, A.y + C.y}, vz[3] = {A.z, A.z + B.z, A.z + C.z};
-        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-        bool whole = false;
+        const float half_w = 0.5f * f.wf, half_h = 0.5f * f.hf;
+        float fxs[3], fys[3], ws[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float xv = (f.mv[0] * vx[c] + f.mv[1] * vy[c]) + (f.mv[2] * vz[c] + f.mv[3]);
-            const float yv = (f.mv[4] * vx[c] + f.mv[5] * vy[c]) + (f.mv[6] * vz[c] + f.mv[7]);
-            const float zv = (f.mv[8] * vx[c] + f.mv[9] * vy[c]) + (f.mv[10] * vz[c] + f.mv[11]);
-            const float w = -zv; // w_clip of a GLM perspective
-            // (the hardware's reciprocal, a unit in the last place off at most: what it feeds is widened by an eighth of a
-            // pixel below, and an exact quotient costs ten instructions)
-            const float rw = __builtin_amdgcn_rcpf(w);
-            const float fx = ((f.p00 * xv) * rw + 1.0f) * (0.5f * f.wf);
-            const float fy = ((f.p11 * yv) * rw + 1.0f) * (0.5f * f.hf);
-            whole = whole || !(w > 1e-30f) || !(fx == fx) || !(fy == fy);
-            xmin = fminf(xmin, fx), xmax = fmaxf(xmax, fx), ymin = fminf(ymin, fy), ymax = fmaxf(ymax, fy);
+            // (fused multiply-adds and the hardware's reciprocal, a unit in the last place off at most: what this feeds is
+            // widened by an eighth of a pixel below; the separate roundings cost twice the instructions and an exact
+            // quotient ten)
+            const float xv = __builtin_fmaf(f.mv[0], vx[c], __builtin_fmaf(f.mv[1], vy[c], __builtin_fmaf(f.mv[2], vz[c], f.mv[3])));
+            const float yv = __builtin_fmaf(f.mv[4], vx[c], __builtin_fmaf(f.mv[5], vy[c], __builtin_fmaf(f.mv[6], vz[c], f.mv[7])));
+            const float zv = __builtin_fmaf(f.mv[8], vx[c], __builtin_fmaf(f.mv[9], vy[c], __builtin_fmaf(f.mv[10], vz[c], f.mv[11])));
+            ws[c] = -zv; // w_clip of a GLM perspective
+            const float rw = __builtin_amdgcn_rcpf(ws[c]);
+            fxs[c] = __builtin_fmaf(xv * rw, half_w * f.p00, half_w); // ((p00 xv / w) + 1) w / 2
+            fys[c] = __builtin_fmaf(yv * rw, half_h * f.p11, half_h);
         }
+        const float xmin = fminf(fminf(fxs[0], fxs[1]), fxs[2]), xmax = fmaxf(fmaxf(fxs[0], fxs[1]), fxs[2]);
+        const float ymin = fminf(fminf(fys[0], fys[1]), fys[2]), ymax = fmaxf(fmaxf(fys[0], fys[1]), fys[2]);
+        // a w that is not clearly positive, or a position that is not a number (a minimum would drop it; a w that is not a
+        // number makes such a position): one comparison per vertex says whether either of its two is
+        const bool whole = !(fminf(fminf(ws[0], ws[1]), ws[2]) > 1e-30f) | __builtin_isunordered(fxs[0], fys[0]) |
+                           __builtin_isunordered(fxs[1], fys[1]) | __builtin_isunordered(fxs[2], fys[2]);
         // pixel centres px + 0.5 inside [xmin - m, xmax + m], clipped to the rectangle that can contain hits
         const float m = 0.125f;
         float fx0 = ceilf(xmin - m - 0.5f), fx1 = floorf(xmax + m - 0.5f);
@@ -1813,15 +1835,18 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
         const float eps = pair_eps(f.ox, f.oy, f.oz, f.dir_abs_max + f.dir_abs_max, A, B, C);
         // the pixel loop, every lane of the wave in step: trip i is the lane's i-th pixel, if it has that many
         const uint32_t cols = some ? x1 - x0 + 1u : 0u, mine = some ? cols * (y1 - y0 + 1u) : 0u;
-        uint32_t trips = mine;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, o));
         uint32_t px = x0, py = y0;
-        for (uint32_t i = 0; i < trips; i++) { // wave-uniform trip count
+        // (dir_at at the pixel's centre with its steps folded into multiply-adds: view-space x = px * sx + tx; roundings of
+        // the size eps already allows for)
+        const float sx = f.inv_w2 * f.inv_p00, tx = __builtin_fmaf(0.5f, sx, -f.inv_p00);
+        const float sy = f.inv_h2 * f.inv_p11, ty = __builtin_fmaf(0.5f, sy, -f.inv_p11);
+        for (uint32_t i = 0; __ballot(i < mine) != 0ull; i++) { // as many trips as the lane with the most pixels has
             bool pass = false;
             if (i < mine) {
-                float dx, dy, dz;
-                dir_at(f, (float)px + 0.5f, (float)py + 0.5f, dx, dy, dz);
+                const float dxv = __builtin_fmaf((float)px, sx, tx), dyv = __builtin_fmaf((float)py, sy, ty);
+                const float dx = __builtin_fmaf(f.d0x, dxv, __builtin_fmaf(f.d1x, dyv, -f.d2x));
+                const float dy = __builtin_fmaf(f.d0y, dxv, __builtin_fmaf(f.d1y, dyv, -f.d2y));
+                const float dz = __builtin_fmaf(f.d0z, dxv, __builtin_fmaf(f.d1z, dyv, -f.d2z));
                 const float det = __builtin_fmaf(dx, P0.x, __builtin_fmaf(dy, P0.y, dz * P0.z));
                 const float un = __builtin_fmaf(dx, P1.x, __builtin_fmaf(dy, P1.y, dz * P1.z));
                 const float vn = __builtin_fmaf(dx, P2.x, __builtin_fmaf(dy, P2.y, dz * P2.z));
@@ -1837,8 +1862,13 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
             if (pass) {
                 if (ap < kPairCap)
                     s_pairs[ap] = make_uint2(at, px | (py << 16));
-                else
-                    scatter_pair(f, k, px, py, A, B, C, vis); // the list is full: this pair right away
+                else { // the list is full: this pair right away
+                    // (the records as values made here, so that what the test computes from them alone is not computed
+                    // ahead of the loop for every triangle)
+                    float4 A2 = A, B2 = B, C2 = C;
+                    asm volatile("" : "+v"(A2.x), "+v"(A2.y), "+v"(A2.z), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(C2.x), "+v"(C2.y), "+v"(C2.z));
+                    scatter_pair(f, k, px, py, A2, B2, C2, vis);
+                }
             }
             if (++px > x1) px = x0, py++;
         }
