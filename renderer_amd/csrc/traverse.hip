@@ -1606,23 +1606,27 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
         entry = make_uint2(__float_as_uint(lo.w), __float_as_uint(hi.w));
         const float grow = 2.0f * f.pad;
         const float cx[2] = {lo.x - grow, hi.x + grow}, cy[2] = {lo.y - grow, hi.y + grow}, cz[2] = {lo.z - grow, hi.z + grow};
-        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, wmin = INFINITY;
         bool whole = false;
+        const float half_w = 0.5f * f.wf, half_h = 0.5f * f.hf;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const float x = cx[c & 1], y = cy[(c >> 1) & 1], z = cz[c >> 2];
-            const float xv = (f.mv[0] * x + f.mv[1] * y) + (f.mv[2] * z + f.mv[3]);
-            const float yv = (f.mv[4] * x + f.mv[5] * y) + (f.mv[6] * z + f.mv[7]);
-            const float zv = (f.mv[8] * x + f.mv[9] * y) + (f.mv[10] * z + f.mv[11]);
+            // (fused multiply-adds and the hardware's reciprocal, a unit in the last place off at most: what this feeds is
+            // widened by an eighth of a pixel below)
+            const float xv = __builtin_fmaf(f.mv[0], x, __builtin_fmaf(f.mv[1], y, __builtin_fmaf(f.mv[2], z, f.mv[3])));
+            const float yv = __builtin_fmaf(f.mv[4], x, __builtin_fmaf(f.mv[5], y, __builtin_fmaf(f.mv[6], z, f.mv[7])));
+            const float zv = __builtin_fmaf(f.mv[8], x, __builtin_fmaf(f.mv[9], y, __builtin_fmaf(f.mv[10], z, f.mv[11])));
             const float w = -zv; // w_clip of a GLM perspective
-            // (the hardware's reciprocal, a unit in the last place off at most: what it feeds is widened by an eighth of a
-            // pixel below, and an exact quotient costs ten instructions)
             const float rw = __builtin_amdgcn_rcpf(w);
-            const float fx = ((f.p00 * xv) * rw + 1.0f) * (0.5f * f.wf);
-            const float fy = ((f.p11 * yv) * rw + 1.0f) * (0.5f * f.hf);
-            whole = whole || !(w > 1e-30f) || !(fx == fx) || !(fy == fy);
+            const float fx = __builtin_fmaf(xv * rw, half_w * f.p00, half_w); // ((p00 xv / w) + 1) w / 2
+            const float fy = __builtin_fmaf(yv * rw, half_h * f.p11, half_h);
+            // (a position that is not a number: a minimum would drop it; a w that is not a number makes such a position)
+            whole = whole | __builtin_isunordered(fx, fy);
+            wmin = fminf(wmin, w);
             xmin = fminf(xmin, fx), xmax = fmaxf(xmax, fx), ymin = fminf(ymin, fy), ymax = fmaxf(ymax, fy);
         }
+        whole = whole | !(wmin > 1e-30f);
         const float edge = (float)pl.block_px, redge = 1.0f / edge; // 8 or 16: exact
         const float hx0 = (float)(f.rx0 & ~(pl.block_px - 1u)), hy0 = (float)(f.ry0 & ~(pl.block_px - 1u));
         const float m = 0.125f;
