@@ -1931,75 +1931,81 @@ __global__ __launch_bounds__(256) void k_scatter_resolve(FrameK f, MeshSource me
 // The same for whole row-major frames whose rows and buffers allow 16-byte accesses, without an occlusion pass: four
 // pixels of a row per lane, 16 bytes per attachment and store (write-through and non-temporal, like the clear: five
 // sixths of these pixels are background).
+// A wave takes a 16 x 16 pixel square, a lane four pixels of one of its rows: neighbouring pixels are won by
+// triangles that lie close together in the sorted arrays, so the square's gathers (slot_of, the winners' records)
+// share cache lines where a run of 256 pixels along one row would not.
+// Where the scene covers the square, two in five of its pixels have a winner: a lane that shaded its own four one
+// after the other ran every step for whichever of the wave's lanes had a hit in that place.  The wave lists its hit
+// pixels in LDS instead and shades them 64 at a time, a lane per listed pixel, whosever it is; the colours go back
+// through LDS to the lanes that store them.
 __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, MeshSource mesh, const float4* __restrict__ TA,
                                                           const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                           const uint32_t* __restrict__ slot_of, uint32_t ntri,
                                                           unsigned long long* __restrict__ vis, Outputs out) {
-#ifndef INV_RESOLVE_TILED
-#define INV_RESOLVE_TILED 1
-#endif
-#if INV_RESOLVE_TILED
-    // A wave takes a 16 x 16 pixel square, a lane four pixels of one of its rows: neighbouring pixels are won by
-    // triangles that lie close together in the sorted arrays, so the square's gathers (slot_of, the winners' records)
-    // share cache lines where a run of 256 pixels along one row would not.
-    const uint32_t squares_x = (f.w + 15u) >> 4, lane = threadIdx.x & 63u;
-    const uint32_t sq = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t px0 = (sq % squares_x) * 16u + (lane & 3u) * 4u, py = (sq / squares_x) * 16u + (lane >> 2);
-    if (px0 >= f.w || py >= f.h) return;
+    // per wave: the square's keys by pixel (pixel 4 * lane + j is lane's j-th), the list of those with a winner, and the
+    // three values of every pixel
+    __shared__ unsigned long long s_key[4][256];
+    __shared__ uint8_t s_list[4][256];
+    __shared__ u32x4_t s_val[4][3][64];
+    const uint32_t squares_x = (f.w + 15u) >> 4, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sq = blockIdx.x * 4u + wave;
+    const uint32_t sx0 = (sq % squares_x) * 16u, sy0 = (sq / squares_x) * 16u;
+    const uint32_t px0 = sx0 + (lane & 3u) * 4u, py = sy0 + (lane >> 2);
+    const bool in_frame = px0 < f.w && py < f.h; // (the frame's width is a multiple of four)
     const uint32_t pix0 = py * f.w + px0;
-#else
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // group of four pixels
-    if (q * 4u >= f.npix) return;
-    const uint32_t pix0 = (uint32_t)(q * 4u), py = pix0 / f.w, px0 = pix0 - py * f.w;
-#endif
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     u64x2* const vp = (u64x2*)(vis + pix0);
-    const u64x2 k01 = vp[0], k23 = vp[1];
+    const u64x2 miss2 = {kMissKey, kMissKey};
+    u64x2 k01 = miss2, k23 = miss2;
+    if (in_frame) k01 = vp[0], k23 = vp[1];
     const unsigned long long keys[4] = {k01.x, k01.y, k23.x, k23.y};
     const uint32_t bg = background_pixel(f.flags);
     u32x4_t col = {bg, bg, bg, bg}, dep = {0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u}, pid = {~0u, ~0u, ~0u, ~0u};
-    if (k01.x != kMissKey || k01.y != kMissKey || k23.x != kMissKey || k23.y != kMissKey) { // some pixel was hit
-        const u64x2 miss2 = {kMissKey, kMissKey};
-        vp[0] = miss2, vp[1] = miss2;
-#ifndef INV_RESOLVE_GROUP
-#define INV_RESOLVE_GROUP 2
-#endif
-        // the lookups of INV_RESOLVE_GROUP pixels, then their records, each set in flight together: a lane's pixels
-        // are independent (fewer at a time: fewer registers, more waves per SIMD)
-        constexpr int G = INV_RESOLVE_GROUP;
+    const bool some = k01.x != kMissKey || k01.y != kMissKey || k23.x != kMissKey || k23.y != kMissKey;
+    if (some) vp[0] = miss2, vp[1] = miss2;
+    if (__ballot(some) != 0ull) { // some pixel of the square was hit (the same for the whole wave)
+        uint32_t n = 0;
 #pragma unroll
-        for (int j0 = 0; j0 < 4; j0 += G) {
-            uint32_t slot[G];
-            bool hit[G];
-#pragma unroll
-            for (int j = 0; j < G; j++) {
-                hit[j] = keys[j0 + j] != kMissKey && (uint32_t)keys[j0 + j] < ntri; // (the second test never fails for keys the first pass wrote)
-                slot[j] = hit[j] && !mesh.xyzw ? slot_of[(uint32_t)keys[j0 + j]] : 0u;
-            }
-            float4 A[G], B[G], C[G];
-            if (mesh.xyzw) { // (the same for every lane) the winners assembled again from the cached mesh, together:
-                uint32_t ids[G]; // a pixel without a hit takes triangle 0 along, which nothing looks at
-#pragma unroll
-                for (int j = 0; j < G; j++) ids[j] = hit[j] ? (uint32_t)keys[j0 + j] : 0u;
-                assemble_records<G>(mesh, ids, A, B, C);
-            } else {
-#pragma unroll
-                for (int j = 0; j < G; j++) A[j] = TA[slot[j]], B[j] = TB[slot[j]], C[j] = TC[slot[j]]; // (slot 0 without a hit)
-            }
-#pragma unroll
-            for (int j = 0; j < G; j++) {
+        for (int j = 0; j < 4; j++) {
+            const bool hit = keys[j] != kMissKey && (uint32_t)keys[j] < ntri; // (the second test never fails for keys the first pass wrote)
+            const uint64_t m = __ballot(hit);
+            if (hit) s_list[wave][n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)(4u * lane + (uint32_t)j);
+            n += (uint32_t)__popcll(m);
+        }
+        ((u64x2*)s_key[wave])[2u * lane] = k01, ((u64x2*)s_key[wave])[2u * lane + 1u] = k23;
+        s_val[wave][0][lane] = col, s_val[wave][1][lane] = dep, s_val[wave][2][lane] = pid;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t e0 = 0; e0 < n; e0 += 64u) { // (wave-uniform)
+            if (e0 + lane < n) {
+                const uint32_t at = s_list[wave][e0 + lane];
+                const unsigned long long key = s_key[wave][at];
+                const uint32_t px = sx0 + ((at >> 2) & 3u) * 4u + (at & 3u), pyy = sy0 + (at >> 4);
+                // (with a cached mesh the winner is assembled again from it: no look-up of its place in the sorted arrays)
+                uint32_t slot = 0u;
+                float4 A, B, C;
+                if (mesh.xyzw) { // (the same for every lane)
+                    assemble_record(mesh, (uint32_t)key, A, B, C);
+                } else {
+                    slot = slot_of[(uint32_t)key];
+                    A = TA[slot], B = TB[slot], C = TC[slot];
+                }
                 float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
                 Hit first = miss_hit();
-                if (hit[j]) {
-                    const Ray ray0 = make_ray(f, px0 + (uint32_t)(j0 + j), py, 0.5f, 0.5f);
-                    mt_test(f, ray0, A[j], B[j], C[j], slot[j], first); // the same test again: the same key, now with its terms
-                    if (first.key != kMissKey) shade_hit(f, first, A[j], B[j], C[j], r, g, b);
-                }
-                col[j0 + j] = pack_pixel(f.flags, r, g, b);
-                dep[j0 + j] = (uint32_t)(first.key >> 32), pid[j0 + j] = (uint32_t)first.key;
+                const Ray ray0 = make_ray(f, px, pyy, 0.5f, 0.5f);
+                mt_test(f, ray0, A, B, C, slot, first); // the same test again: the same key, now with its terms
+                if (first.key != kMissKey) shade_hit(f, first, A, B, C, r, g, b);
+                uint32_t* const v = (uint32_t*)&s_val[wave][0][0];
+                v[at] = pack_pixel(f.flags, r, g, b), v[256u + at] = (uint32_t)(first.key >> 32), v[512u + at] = (uint32_t)first.key;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        col = s_val[wave][0][lane], dep = s_val[wave][1][lane], pid = s_val[wave][2][lane];
     }
+    if (!in_frame) return;
 #define INV_ST16_NT(p, v) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory")
     if (out.color) INV_ST16_NT((uint32_t*)out.color + pix0, col);
     if (out.depth) INV_ST16_NT((uint32_t*)out.depth + pix0, dep);
@@ -2443,11 +2449,7 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
         if (f.rowmajor && f.nranks == 1 && !ao.rays && f.w % 4u == 0 && aligned16(out.color) && aligned16(out.depth) &&
             aligned16(out.primid)) {
-#if INV_RESOLVE_TILED
-            const unsigned resolve_blocks = (((f.w + 15u) >> 4) * ((f.h + 15u) >> 4) + 3u) / 4u;
-#else
-            const unsigned resolve_blocks = (unsigned)((f.npix / 4 + 255) / 256);
-#endif
+            const unsigned resolve_blocks = (((f.w + 15u) >> 4) * ((f.h + 15u) >> 4) + 3u) / 4u; // a wave per 16 x 16 square
             hipLaunchKernelGGL(k_scatter_resolve4, dim3(resolve_blocks), dim3(256), 0, s, f, mesh,
                                (const float4*)sc.triA, (const float4*)sc.triB, (const float4*)sc.triC,
                                (const uint32_t*)sc.slot_of, sc.ntri, vis, out);
