@@ -1710,14 +1710,17 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
 #define INV_SCATTER_PER_LANE 2
 #endif
 constexpr uint32_t kScatterPerLane = INV_SCATTER_PER_LANE; // triangles per lane of the triangle pass
-constexpr uint32_t kPairCap = 1024; // (triangle, pixel) pairs a workgroup of the triangle pass lists before it tests them
+// (triangle, pixel) pairs a workgroup of the triangle pass lists before it tests them (some 150 where triangles are much
+// smaller than a pixel; with 1024 the workgroup's LDS was 40 bytes more than a fifth of a CU's, and the pass is a chain
+// of round trips that wants every wave it can get: 58.2 -> 52.7 us per frame of five million triangles)
+constexpr uint32_t kPairCap = 512;
 
 // The exact test of one (triangle, pixel) pair and the key minimum in the visibility buffer.
-__device__ __forceinline__ void scatter_pair(const FrameK& f, uint32_t k, uint32_t px, uint32_t py, const float4& A,
+__device__ __forceinline__ void scatter_pair(const FrameK& f, uint32_t px, uint32_t py, const float4& A,
                                              const float4& B, const float4& C, unsigned long long* __restrict__ vis) {
     const Ray ray = make_ray(f, px, py, 0.5f, 0.5f);
     Hit best = miss_hit();
-    mt_test(f, ray, A, B, C, k, best);
+    mt_test(f, ray, A, B, C, 0u, best); // (the key carries the primitive id: A.w)
     if (best.key != kMissKey) atomicMin(&vis[(size_t)py * f.w + px], (unsigned long long)best.key);
 }
 
@@ -1733,7 +1736,7 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
                                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                            uint32_t ntri, unsigned long long* __restrict__ vis) {
     __shared__ uint32_t s_nfront, s_npairs;
-    __shared__ uint32_t s_front[256 * kScatterPerLane]; // the listed triangles, and their records (read once from memory)
+    // the listed triangles' records (read once from memory)
     __shared__ float4 s_recA[256 * kScatterPerLane], s_recB[256 * kScatterPerLane], s_recC[256 * kScatterPerLane];
     __shared__ uint2 s_pairs[kPairCap]; // (place in the list, px | py << 16)
     const uint32_t lane = threadIdx.x & 63u;
@@ -1782,7 +1785,7 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
 #pragma unroll
         for (uint32_t u = 0; u < kScatterPerLane; u++) {
             const uint32_t mine = at + (uint32_t)__popcll(mask[u] & ((1ull << lane) - 1ull));
-            if (front[u]) s_front[mine] = (blockIdx.x * kScatterPerLane + u) * 256u + threadIdx.x, s_recA[mine] = rA[u], s_recB[mine] = rB[u], s_recC[mine] = rC[u];
+            if (front[u]) s_recA[mine] = rA[u], s_recB[mine] = rB[u], s_recC[mine] = rC[u];
             at += (uint32_t)__popcll(mask[u]);
         }
     }
@@ -1790,7 +1793,7 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
     const uint32_t nfront = s_nfront;
     for (uint32_t base = threadIdx.x & ~63u; base < nfront; base += 256u) { // wave-uniform: 64 listed triangles a trip
         const bool have = base + lane < nfront;
-        const uint32_t at = have ? base + lane : 0u, k = s_front[at];
+        const uint32_t at = have ? base + lane : 0u;
         const float4 A = s_recA[at], B = s_recB[at], C = s_recC[at];
         float4 P0, P1, P2;
         fold_triangle(f.ox, f.oy, f.oz, A, B, C, P0, P1, P2);
@@ -1871,7 +1874,7 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
                     // ahead of the loop for every triangle)
                     float4 A2 = A, B2 = B, C2 = C;
                     asm volatile("" : "+v"(A2.x), "+v"(A2.y), "+v"(A2.z), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(C2.x), "+v"(C2.y), "+v"(C2.z));
-                    scatter_pair(f, k, px, py, A2, B2, C2, vis);
+                    scatter_pair(f, px, py, A2, B2, C2, vis);
                 }
             }
             if (++px > x1) px = x0, py++;
@@ -1881,7 +1884,7 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
     const uint32_t npairs = min(s_npairs, kPairCap);
     for (uint32_t q = threadIdx.x; q < npairs; q += 256u) {
         const uint2 e = s_pairs[q];
-        scatter_pair(f, s_front[e.x], e.y & 0xFFFFu, e.y >> 16, s_recA[e.x], s_recB[e.x], s_recC[e.x], vis);
+        scatter_pair(f, e.y & 0xFFFFu, e.y >> 16, s_recA[e.x], s_recB[e.x], s_recC[e.x], vis);
     }
 }
 
