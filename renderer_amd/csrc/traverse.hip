@@ -1711,9 +1711,14 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
 #endif
 constexpr uint32_t kScatterPerLane = INV_SCATTER_PER_LANE; // triangles per lane of the triangle pass
 // (triangle, pixel) pairs a workgroup of the triangle pass lists before it tests them (some 150 where triangles are much
-// smaller than a pixel; with 1024 the workgroup's LDS was 40 bytes more than a fifth of a CU's, and the pass is a chain
-// of round trips that wants every wave it can get: 58.2 -> 52.7 us per frame of five million triangles)
-constexpr uint32_t kPairCap = 512;
+// smaller than a pixel; what no longer fits is tested on the spot).  The list decides how many workgroups share a CU's
+// LDS, and the pass is a chain of round trips that wants every wave it can get: with 1024 entries the workgroup was 40
+// bytes above a fifth of a CU's LDS (58.2 us per frame of five million triangles), with 512 five fit (52.7 us), with 256
+// six (49.4 us).  Six are taken while the triangle arrays fit the Infinity Cache; a scene of 69 million triangles, which
+// waits for HBM, was 1.4 % slower with six than with five.
+template <int WAVES>
+constexpr uint32_t kPairCap = WAVES >= 6 ? 256u : 512u;
+constexpr uint64_t kScatterSixBytes = 256ull << 20; // triangle arrays up to this size: six workgroups per CU
 
 // The exact test of one (triangle, pixel) pair and the key minimum in the visibility buffer.
 __device__ __forceinline__ void scatter_pair(const FrameK& f, uint32_t px, uint32_t py, const float4& A,
@@ -1732,13 +1737,14 @@ __device__ __forceinline__ void scatter_pair(const FrameK& f, uint32_t px, uint3
 // wave at 42 % of lanes.)
 // (Assembling the triangles again from a mesh that the caches hold, as the resolve pass does with its winners, was
 // no faster here: 72 against 71 us for five million triangles.  The pass is not waiting for its 48 bytes per triangle.)
-__global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float4* __restrict__ TA,
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_scatter_triangles(FrameK f, const float4* __restrict__ TA,
                                                            const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                            uint32_t ntri, unsigned long long* __restrict__ vis) {
     __shared__ uint32_t s_nfront, s_npairs;
     // the listed triangles' records (read once from memory)
     __shared__ float4 s_recA[256 * kScatterPerLane], s_recB[256 * kScatterPerLane], s_recC[256 * kScatterPerLane];
-    __shared__ uint2 s_pairs[kPairCap]; // (place in the list, px | py << 16)
+    __shared__ uint2 s_pairs[kPairCap<WAVES>]; // (place in the list, px | py << 16)
     const uint32_t lane = threadIdx.x & 63u;
     if (threadIdx.x == 0) s_nfront = 0, s_npairs = 0;
     __syncthreads();
@@ -1867,21 +1873,22 @@ __global__ __launch_bounds__(256) void k_scatter_triangles(FrameK f, const float
             }
             const uint32_t ap = wave_append(&s_npairs, pass, lane);
             if (pass) {
-                if (ap < kPairCap)
+                if (ap < kPairCap<WAVES>)
                     s_pairs[ap] = make_uint2(at, px | (py << 16));
                 else { // the list is full: this pair right away
-                    // (the records as values made here, so that what the test computes from them alone is not computed
-                    // ahead of the loop for every triangle)
-                    float4 A2 = A, B2 = B, C2 = C;
-                    asm volatile("" : "+v"(A2.x), "+v"(A2.y), "+v"(A2.z), "+v"(B2.x), "+v"(B2.y), "+v"(B2.z), "+v"(C2.x), "+v"(C2.y), "+v"(C2.z));
-                    scatter_pair(f, px, py, A2, B2, C2, vis);
+                    // (the records read again, from a place the optimiser cannot see through: what the test computes from
+                    // them alone is then not computed ahead of the loop for every triangle, and they need not stay in
+                    // registers through it)
+                    uint32_t at2 = at;
+                    asm volatile("" : "+v"(at2));
+                    scatter_pair(f, px, py, s_recA[at2], s_recB[at2], s_recC[at2], vis);
                 }
             }
             if (++px > x1) px = x0, py++;
         }
     }
     __syncthreads();
-    const uint32_t npairs = min(s_npairs, kPairCap);
+    const uint32_t npairs = min(s_npairs, kPairCap<WAVES>);
     for (uint32_t q = threadIdx.x; q < npairs; q += 256u) {
         const uint2 e = s_pairs[q];
         scatter_pair(f, e.y & 0xFFFFu, e.y >> 16, s_recA[e.x], s_recB[e.x], s_recC[e.x], vis);
@@ -2446,9 +2453,15 @@ hipError_t launch_render_bvh(hipStream_t s, const FrameK& f, const DeviceScene& 
         const MeshSource mesh = mesh_source(sc.mesh_cached && mesh_draw_enabled() ? (const float4*)sc.xyzw : nullptr, sc.idx,
                                                  sc.translations, sc.base_ntri, sc.ninst);
         // (nothing to try when the scene lies outside the frame: the resolve pass then stores clear values only)
-        if (f.rx1 > f.rx0 && f.ry1 > f.ry0)
-            hipLaunchKernelGGL(k_scatter_triangles, dim3((sc.ntri + 256u * kScatterPerLane - 1u) / (256u * kScatterPerLane)), dim3(256), 0, s, f, (const float4*)sc.triA,
-                               (const float4*)sc.triB, (const float4*)sc.triC, sc.ntri, vis);
+        if (f.rx1 > f.rx0 && f.ry1 > f.ry0) {
+            const dim3 grid((sc.ntri + 256u * kScatterPerLane - 1u) / (256u * kScatterPerLane));
+            if ((uint64_t)sc.ntri * 48u <= kScatterSixBytes)
+                hipLaunchKernelGGL(k_scatter_triangles<6>, grid, dim3(256), 0, s, f, (const float4*)sc.triA, (const float4*)sc.triB,
+                                   (const float4*)sc.triC, sc.ntri, vis);
+            else
+                hipLaunchKernelGGL(k_scatter_triangles<5>, grid, dim3(256), 0, s, f, (const float4*)sc.triA, (const float4*)sc.triB,
+                                   (const float4*)sc.triC, sc.ntri, vis);
+        }
         const auto aligned16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
         if (f.rowmajor && f.nranks == 1 && !ao.rays && f.w % 4u == 0 && aligned16(out.color) && aligned16(out.depth) &&
             aligned16(out.primid)) {
