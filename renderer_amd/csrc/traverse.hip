@@ -1952,9 +1952,9 @@ __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, MeshSource m
                                                           const float4* __restrict__ TB, const float4* __restrict__ TC,
                                                           const uint32_t* __restrict__ slot_of, uint32_t ntri,
                                                           unsigned long long* __restrict__ vis, Outputs out) {
-    // per wave: the square's keys by pixel (pixel 4 * lane + j is lane's j-th), the list of those with a winner, and the
-    // three values of every pixel
-    __shared__ unsigned long long s_key[4][256];
+    // per wave: the square's winners by pixel (the primitive id of the key; pixel 4 * lane + j is lane's j-th), the list
+    // of the pixels that have one, and the three values of every pixel
+    __shared__ u32x4_t s_prim[4][64];
     __shared__ uint8_t s_list[4][256];
     __shared__ u32x4_t s_val[4][3][64];
     const uint32_t squares_x = (f.w + 15u) >> 4, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, MeshSource m
             if (hit) s_list[wave][n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)(4u * lane + (uint32_t)j);
             n += (uint32_t)__popcll(m);
         }
-        ((u64x2*)s_key[wave])[2u * lane] = k01, ((u64x2*)s_key[wave])[2u * lane + 1u] = k23;
+        s_prim[wave][lane] = u32x4_t{(uint32_t)k01.x, (uint32_t)k01.y, (uint32_t)k23.x, (uint32_t)k23.y};
         s_val[wave][0][lane] = col, s_val[wave][1][lane] = dep, s_val[wave][2][lane] = pid;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1990,15 +1990,15 @@ __global__ __launch_bounds__(256) void k_scatter_resolve4(FrameK f, MeshSource m
         for (uint32_t e0 = 0; e0 < n; e0 += 64u) { // (wave-uniform)
             if (e0 + lane < n) {
                 const uint32_t at = s_list[wave][e0 + lane];
-                const unsigned long long key = s_key[wave][at];
+                const uint32_t prim = ((const uint32_t*)&s_prim[wave][0])[at];
                 const uint32_t px = sx0 + ((at >> 2) & 3u) * 4u + (at & 3u), pyy = sy0 + (at >> 4);
                 // (with a cached mesh the winner is assembled again from it: no look-up of its place in the sorted arrays)
                 uint32_t slot = 0u;
                 float4 A, B, C;
                 if (mesh.xyzw) { // (the same for every lane)
-                    assemble_record(mesh, (uint32_t)key, A, B, C);
+                    assemble_record(mesh, prim, A, B, C);
                 } else {
-                    slot = slot_of[(uint32_t)key];
+                    slot = slot_of[prim];
                     A = TA[slot], B = TB[slot], C = TC[slot];
                 }
                 float r = 0.0f, g = 0.0f, b = 0.0f; // clear colour (src/invert.cpp:742)
