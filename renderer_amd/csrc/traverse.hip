@@ -1593,12 +1593,16 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
     __shared__ uint2 s_entry[256];
     __shared__ uint32_t s_off[257]; // pairs before record r of this workgroup; [rpw] = all pairs
     __shared__ uint32_t s_wave[4];
+    // bins the workgroup's pairs fall into: bin + 1 (0: free), pairs counted, places reserved in the bin's list
+    constexpr uint32_t kBinHashBits = 9, kBinHash = 1u << kBinHashBits;
+    __shared__ uint32_t s_hkey[kBinHash], s_hcnt[kBinHash], s_hbase[kBinHash];
     const FrameK& f = b.fr[blockIdx.y].f;
     const TilePlan& pl = b.fr[blockIdx.y].pl;
     if (!pl.bin_count || pl.ntiles == 0) return; // block-uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t i = blockIdx.x * rpw + tid;
     const uint32_t tiles_x = pl.tiles_x, tiles_y = pl.ntiles / pl.tiles_x;
+    for (uint32_t h = tid; h < kBinHash; h += 256u) s_hkey[h] = 0u, s_hcnt[h] = 0u; // (barriers below before its first use)
     uint32_t bx0 = 1, bx1 = 0, by0 = 1, by1 = 0; // empty
     uint2 entry = make_uint2(0u, 0u);
     if (tid < rpw && i < nfine) {
@@ -1656,14 +1660,18 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
     if (tid == 255u) s_off[256] = before + incl;
     __syncthreads();
     const uint32_t npairs = s_off[256];
+    // The records of a workgroup lie together, so its pairs fall into few bins, and so do its neighbours' at the same
+    // moment: an update of a bin's counter per pair made the pass wait for some sixty updates of one address after
+    // another.  The pairs are counted per bin in LDS first (a small hash table; a pair that finds no place in it
+    // updates the bin's counter itself, as before), then one update per bin and workgroup reserves the places.
     for (uint32_t base = 0; base < npairs; base += 1024u) { // block-uniform
-        uint32_t bin[4], at[4];
+        uint32_t bin[4], at[4], slot[4];
         uint2 e[4];
         bool go[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = base + (uint32_t)u * 256u + tid;
-            go[u] = false, bin[u] = 0, at[u] = 0, e[u] = make_uint2(0u, 0u);
+            go[u] = false, bin[u] = 0, at[u] = 0, slot[u] = kBinHash, e[u] = make_uint2(0u, 0u);
             if (p < npairs) {
                 // the record this pair belongs to: the last r with s_off[r] <= p
                 uint32_t r = 0;
@@ -1678,11 +1686,36 @@ __global__ __launch_bounds__(256) void k_bin_ranges(Batch b, const float4* __res
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (go[u]) at[u] = atomicAdd(&pl.bin_count[bin[u]], 1u);
+        for (int u = 0; u < 4; u++) {
+            if (go[u]) {
+                uint32_t h = (bin[u] * 2654435761u) >> (32 - kBinHashBits);
+                for (int probe = 0; probe < 8; probe++) {
+                    const uint32_t was = atomicCAS(&s_hkey[h], 0u, bin[u] + 1u);
+                    if (was == 0u || was == bin[u] + 1u) {
+                        slot[u] = h;
+                        break;
+                    }
+                    h = (h + 1u) & (kBinHash - 1u);
+                }
+                at[u] = slot[u] != kBinHash ? atomicAdd(&s_hcnt[slot[u]], 1u) : atomicAdd(&pl.bin_count[bin[u]], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < kBinHash; i += 256u)
+            if (s_hkey[i] != 0u) s_hbase[i] = atomicAdd(&pl.bin_count[s_hkey[i] - 1u], s_hcnt[i]);
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (go[u] && at[u] < (uint32_t)kRangeCap) pl.bin_list[(size_t)bin[u] * (uint32_t)kRangeCap + at[u]] = e[u];
+        for (int u = 0; u < 4; u++) {
+            if (go[u]) {
+                const uint32_t place = slot[u] != kBinHash ? s_hbase[slot[u]] + at[u] : at[u];
+                if (place < (uint32_t)kRangeCap) pl.bin_list[(size_t)bin[u] * (uint32_t)kRangeCap + place] = e[u];
+            }
+        }
+        if (base + 1024u < npairs) { // (block-uniform) the table again empty for the next pairs
+            __syncthreads();
+            for (uint32_t i = tid; i < kBinHash; i += 256u) s_hkey[i] = 0u, s_hcnt[i] = 0u;
+            __syncthreads();
+        }
     }
 }
 
