@@ -82,6 +82,31 @@ def test_fine_cut_of_the_large_instanced_scene(gpu_ctx, bunny_mesh):
     scene.close()
 
 
+def test_records_that_touch_more_bins_than_a_workgroup_counts_in_lds(oracle, gpu_ctx):
+    """The binning pass counts a workgroup's (record, bin) pairs per bin in a 512-entry table in LDS and lets a pair that
+    finds no place there update the bin's counter itself.  Here 64 triangles as large as the scene sit among 20 000 small
+    ones (a scene of that size is binned by default): the records that hold them touch every one of the few thousand
+    bins of the frame, far more than the table has entries."""
+    xyz, faces = objfmt.random_soup(20000, seed=21, size=0.004)
+    big, _ = objfmt.random_soup(64, seed=22, lo=(-0.02, 0.09, -0.04), hi=(0.0, 0.13, 0.04), size=0.09)
+    xyz = np.concatenate([xyz, big])
+    faces = np.arange(len(xyz), dtype=np.uint32).reshape(-1, 3)
+    xyzw = np.zeros((len(xyz), 4), np.float32)
+    xyzw[:, :3] = xyz
+    idx = faces.reshape(-1).astype(np.uint32)
+    scene = R.Scene(gpu_ctx, R.Mesh.from_arrays(xyzw, idx))
+    w = h = 1536
+    cam, ocam = R.camera_reference(w, h), oracle.camera_reference(w, h)
+    for flags in (0, R.TILE_TRAVERSAL):
+        prm = R.make_params(w, h, flags=flags)
+        assert scene.draw_path(cam, prm) & R.api.PATH_BINNED
+        got = scene.render(cam, prm)
+        want = oracle.render_bvh(xyzw, idx, ocam, common.oracle_params(oracle, prm))
+        common.assert_frames_equal(got, want, "large and small triangles, flags=%d" % flags)
+    assert (got[2] >= 60000).sum() > 100000  # the large ones cover a good part of the frame
+    scene.close()
+
+
 _PARITY_NAMES = ("config1 or config2 or shading or jittered or samples_in or odd_extents or moved_camera or soup or tiny "
                  "or sharding or sparse_composite or turntable or in_flight or batched_draws or overflow or "
                  "camera_inside or ambient or instanced or ray_along or 8k")
